@@ -1,0 +1,121 @@
+/*
+ * tedm_hip.h -- C ABI of libtedm_hip.so, the MI355X (gfx950) implementation of TEDM's
+ * diffusion-UNet denoising hot path.
+ *
+ * The reference (mmr12/TEDM) is pure Python and has no FFI; the boundary it offers for this
+ * path is the nn.Module surface of models/unet_model.py:246-368 (`Unet`), wrapped by
+ * models/diffusion_model.py:50-203 (`DiffusionModel`) and models/datasetDM_model.py:30-88
+ * (`DatasetDM`).  Each entry point below names the reference interface it stands in for.
+ * The Python facade `tedm_amd.unet.Unet` binds these with ctypes.
+ *
+ * Conventions: every function returns 0 on success or a negative TEDM_E* code and never
+ * throws; `tedm_last_error()` gives a thread-local message.  All device pointers are
+ * BORROWED for the duration of the call (the caller -- PyTorch's allocator -- owns them),
+ * except packed weights, which the handle owns.  Kernels are enqueued on the caller's HIP
+ * stream (`stream` is a hipStream_t passed as void*); nothing synchronises implicitly.
+ * A handle is not thread-safe: one per process / GPU.
+ */
+#ifndef TEDM_HIP_H
+#define TEDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEDM_OK            0
+#define TEDM_EINVAL       -1   /* bad argument / unsupported configuration */
+#define TEDM_ENOKEY       -2   /* unknown state-dict key */
+#define TEDM_EHIP         -3   /* HIP runtime error */
+#define TEDM_ENOMEM       -4   /* workspace too small / allocation failed */
+#define TEDM_ESTATE       -5   /* call order (e.g. forward before pack) */
+
+#define TEDM_MAX_LEVELS    8
+
+/* Arithmetic mode of the MFMA contractions (convs, 1x1 projections). */
+#define TEDM_PREC_BF16X3   0   /* default: bf16 hi/lo split, 3 MFMAs, fp32 accumulate (~2^-17 operand error) */
+#define TEDM_PREC_BF16     1   /* single bf16 MFMA, fp32 accumulate (fast; eps error ~1e-2, fails the 1e-3 gate) */
+
+/* forward flags */
+#define TEDM_FWD_TAPS_ONLY   (1 << 0)  /* skip ups[last][3], final_res_block, final_conv (feature extraction; eps_out may be NULL) */
+#define TEDM_FWD_TRACE       (1 << 1)  /* keep every module output alive in the workspace and record it (tests) */
+#define TEDM_FWD_PREC_SHIFT  8         /* bits 8..11: TEDM_PREC_* */
+
+typedef struct tedm_unet tedm_unet;
+
+/* Mirrors the constructor of models/unet_model.py:247-259 (`Unet.__init__`). */
+typedef struct tedm_unet_cfg {
+    int dim;                       /* base width (reference default 64) */
+    int init_dim;                  /* 0 => dim */
+    int out_dim;                   /* 0 => channels */
+    int n_mults;                   /* len(dim_mults), <= TEDM_MAX_LEVELS */
+    int dim_mults[TEDM_MAX_LEVELS];
+    int channels;                  /* input image channels (TEDM forces 1, train.py:25) */
+    int groups;                    /* resnet_block_groups (8) */
+    int heads;                     /* attention heads (4)   -- unet_model.py:180,217 */
+    int dim_head;                  /* attention head width (32) */
+} tedm_unet_cfg;
+
+/* Unet.__init__ (models/unet_model.py:247-331): builds the layer plan and allocates the
+ * handle-owned packed-weight buffers on the current HIP device. */
+int  tedm_unet_create(const tedm_unet_cfg* cfg, tedm_unet** out);
+void tedm_unet_destroy(tedm_unet* h);
+
+/* Unet.state_dict() surface (276 tensors for the default model). */
+int         tedm_unet_num_params(const tedm_unet* h);
+const char* tedm_unet_param_key(const tedm_unet* h, int i);
+long long   tedm_unet_param_numel(const tedm_unet* h, int i);
+
+/* nn.Module.load_state_dict / parameter binding: `dev_ptr` is the fp32, contiguous device
+ * tensor in the REFERENCE layout (conv OIHW, linear (out,in), norm (C), LayerNorm.g (1,C,1,1)).
+ * The pointer is recorded, not copied; call tedm_unet_pack() after (re)binding or after the
+ * optimizer changed the values. */
+int tedm_unet_set_param(tedm_unet* h, const char* key, const void* dev_ptr, long long numel);
+
+/* Repack all bound weights into the kernels' internal layouts (bf16 hi/lo MFMA fragment
+ * order, concatenated FiLM projection).  Enqueued on `stream`. */
+int tedm_unet_pack(tedm_unet* h, void* stream);
+
+/* Workspace size in bytes for a forward of the given shape / flags. */
+size_t tedm_unet_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags);
+
+/* Unet.forward(x, timestep) (models/unet_model.py:333-368).
+ *   x        (B, channels, H, W) fp32, NCHW contiguous
+ *   t        (B,) fp32 timesteps, or NULL => no time conditioning (timestep=None, :337)
+ *   eps_out  (B, out_dim, H, W) fp32, NCHW contiguous
+ *   feat_out NULL, or 4 (n_mults) device pointers receiving the outputs of ups[i][2]
+ *            (the tensors models/datasetDM_model.py:50-53 hooks) in NHWC: (B, h_i, w_i, C_i) fp32;
+ *            individual entries may be NULL.
+ * H and W must be divisible by 2^(n_mults-1). */
+int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H, int W,
+                      float* eps_out, float* const* feat_out,
+                      void* workspace, size_t workspace_bytes, void* stream, int flags);
+
+/* After a forward with TEDM_FWD_TRACE: named module outputs living in the workspace (NHWC). */
+int         tedm_unet_trace_count(const tedm_unet* h);
+const char* tedm_unet_trace_name(const tedm_unet* h, int i);
+int         tedm_unet_trace_info(const tedm_unet* h, int i, size_t* byte_offset, int* shape4 /* B,H,W,C */);
+
+/* DiffusionModel.forward_diffusion_model (models/diffusion_model.py:176-203) with the optional
+ * x*2-1 of DiffusionModel.forward (:169-170) folded in:
+ *   x_t[b] = sqrt_acp[t[b]] * (normalize ? 2*x0[b]-1 : x0[b]) + sqrt_1macp[t[b]] * noise[b]
+ * x0, noise, x_t: (B, chw) fp32; t: (B,) int64; coefficient tables: (T,) fp32. */
+int tedm_q_sample(const float* x0, const float* noise, const int64_t* t,
+                  const float* sqrt_acp, const float* sqrt_1macp, int T,
+                  float* x_t, int B, long long chw, int normalize, void* stream);
+
+/* DatasetDM.extract_features' resize+concat (models/datasetDM_model.py:80-83): nearest-upsample
+ * one NHWC tap (B,h,w,C) to (S,S) and write it into channels [c_off, c_off+C) of the NCHW
+ * feature tensor (B, C_total, S, S) fp32. */
+int tedm_tap_to_features(const float* tap, int B, int h, int w, int C,
+                         float* feats, int C_total, int c_off, int S, void* stream);
+
+const char* tedm_last_error(void);
+const char* tedm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEDM_HIP_H */

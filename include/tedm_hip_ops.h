@@ -1,0 +1,38 @@
+/*
+ * tedm_hip_ops.h -- op-level entry points of libtedm_hip.so used by the parity tests and the
+ * tuning harness.  They wrap single kernels of the hot path so a failure in the whole-UNet
+ * parity test can be localised; the product path (tedm_hip.h) does not need them.
+ */
+#ifndef TEDM_HIP_OPS_H
+#define TEDM_HIP_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One nn.Conv2d (models/unet_model.py:43,49,122,156,185,188,221,222,307,323) through the NHWC
+ * implicit-GEMM MFMA kernel, including the fusions the UNet uses:
+ *   x1 (B,H,W,C1) [+ x2 (B,H,W,C2) virtual channel concat], optional nearest x2 upsample,
+ *   prologue: GroupNorm-apply+FiLM+SiLU folded to silu(gn_a[b][c]*x + gn_b[b][c])   (gn_a != NULL), or
+ *             channel LayerNorm  ln_g[c]*(x*rstd - mean*rstd), ln_stats (B*H*W,2) = (rstd, mean*rstd);
+ *   weight_oihw (Cout,C1+C2,k,k) fp32 in the reference layout (packed internally), bias (Cout) or NULL;
+ *   epilogue: out = conv + bias + [add | silu(add_a[b][c]*add + add_b[b][c])];
+ *   stats: per-channel partial slab, mode 1: (B,E,Cout,2) sum/sumsq, mode 2: (B,E,Cout) max; E is
+ *          returned in *stats_entries (and by tedm_op_conv2d_stats_entries).
+ * Supported geometries: k=3 s=1 p=1 (optionally upsample), k=4 s=2 p=1, k=1 s=1 p=0.
+ * Synchronises the stream before returning (test helper). */
+int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int H, int W,
+                   const float* weight_oihw, const float* bias, int Cout, int k, int stride, int upsample,
+                   const float* gn_a, const float* gn_b, const float* ln_g, const float* ln_stats,
+                   const float* add, const float* add_a, const float* add_b,
+                   float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream);
+int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
+
+/* Tuning knobs (benchmark harness): "conv_tile_wide" = 0|1|2 selects the workgroup tile used for
+ * convolutions with >= 128 output channels (conv_igemm.hip). */
+int tedm_set_tuning(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""tedm_amd -- MI355X-native implementation of TEDM's diffusion-UNet denoising hot path.
+
+Host side (this package): nn.Module facades with the reference's surface
+(models/unet_model.py `Unet`, models/diffusion_model.py `DiffusionModel`,
+models/datasetDM_model.py `DatasetDM`).  Compute: hand-written HIP kernels for gfx950 in
+tedm_amd/csrc behind the C ABI of include/tedm_hip.h (libtedm_hip.so, loaded with ctypes).
+"""
+from .unet import Unet                      # noqa: F401
+from .diffusion import DiffusionModel       # noqa: F401
+from .dataset_dm import DatasetDM           # noqa: F401
+from .weights import load_synth_weights, synth_state_dict   # noqa: F401
+
+__all__ = ['Unet', 'DiffusionModel', 'DatasetDM', 'load_synth_weights', 'synth_state_dict']

@@ -1,0 +1,79 @@
+"""ctypes binding of libtedm_hip.so (C ABI: include/tedm_hip.h, include/tedm_hip_ops.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / 'libtedm_hip.so'
+
+TEDM_MAX_LEVELS = 8
+PREC_BF16X3, PREC_BF16 = 0, 1
+FWD_TAPS_ONLY, FWD_TRACE, FWD_PREC_SHIFT = 1 << 0, 1 << 1, 8
+PREC_BY_NAME = {'bf16x3': PREC_BF16X3, 'bf16': PREC_BF16}
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [('dim', C.c_int), ('init_dim', C.c_int), ('out_dim', C.c_int), ('n_mults', C.c_int),
+                ('dim_mults', C.c_int * TEDM_MAX_LEVELS), ('channels', C.c_int), ('groups', C.c_int),
+                ('heads', C.c_int), ('dim_head', C.c_int)]
+
+
+class TedmError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    'tedm_last_error': (C.c_char_p, []),
+    'tedm_version': (C.c_char_p, []),
+    'tedm_unet_create': (C.c_int, [C.POINTER(UnetCfg), C.POINTER(_P)]),
+    'tedm_unet_destroy': (None, [_P]),
+    'tedm_unet_num_params': (C.c_int, [_P]),
+    'tedm_unet_param_key': (C.c_char_p, [_P, C.c_int]),
+    'tedm_unet_param_numel': (C.c_longlong, [_P, C.c_int]),
+    'tedm_unet_set_param': (C.c_int, [_P, C.c_char_p, _P, C.c_longlong]),
+    'tedm_unet_pack': (C.c_int, [_P, _P]),
+    'tedm_unet_workspace_bytes': (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_unet_forward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P), _P, C.c_size_t, _P, C.c_int]),
+    'tedm_unet_trace_count': (C.c_int, [_P]),
+    'tedm_unet_trace_name': (C.c_char_p, [_P, C.c_int]),
+    'tedm_unet_trace_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'tedm_q_sample': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_longlong, C.c_int, _P]),
+    'tedm_tap_to_features': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    'tedm_set_tuning': (C.c_int, [C.c_char_p, C.c_int]),
+    'tedm_op_conv2d': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
+                                  C.POINTER(C.c_int), C.c_int, _P]),
+    'tedm_op_conv2d_stats_entries': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get('TEDM_HIP_LIB', LIB_PATH))
+        if not path.exists():
+            raise ImportError(
+                f'{path} not found: build it with `python -m tedm_amd.build` (hipcc, gfx950). '
+                'tedm_amd has no CPU/PyTorch fallback for the UNet hot path.')
+        handle = C.CDLL(str(path))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = lib().tedm_last_error().decode(errors='replace')
+        raise TedmError(f'{what or "libtedm_hip"} failed (code {rc}): {msg}')

@@ -1,0 +1,269 @@
+// attention.hip -- LinearAttention (models/unet_model.py:178-210) and the bottleneck Attention
+// (:213-241) on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (fp32 in, fp32 fmaf
+// chain out: no precision split needed; these contractions are 1.4 % of the FLOPs).
+//
+// Operand maps (cdna guide section 3): A[i][k]: lane = (k<<5)|i ; B[k][j]: lane = (k<<5)|j ;
+// C/D: column j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// A 32x32 accumulator is therefore directly the B operand of a following product that sums
+// over its ROW index: k-step s of the next MFMA takes accumulator register s.
+//
+// qkv layout: (B, hw, 3*heads*32) fp32, channels [q | k | v], head-major, dim_head = 32.
+#include "common.h"
+#include "ops.h"
+#include "../../include/tedm_hip.h"
+
+namespace {
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP)
+
+TEDM_DEVFN int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// ---------------------------------------------------------------------------------------
+// linear attention, pass 1: per (sample, head, pixel split)
+//   ctx_p[d][e] = sum_n exp(k[n][d] - kmax[d]) * v[n][e],   z_p[d] = sum_n exp(k[n][d] - kmax[d])
+// kmax comes from the to_qkv epilogue (max slab), so a single sweep suffices.  Each lane streams
+// its own (pixel parity, channel) element straight from HBM: 2 x 128-B segments per load, no LDS.
+__global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ kmax,
+                                                          int B, long long hw, int heads, int S, long long pps,
+                                                          float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, r = lane & 31, kk = lane >> 5;
+    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= (long long)B * S * heads) return;
+    const int head = (int)(gid % heads);
+    const int s = (int)((gid / heads) % S);
+    const int b = (int)(gid / ((long long)heads * S));
+    const int C3 = 3 * heads * 32;
+    const long long p_beg = s * pps, p_end = (p_beg + pps < hw) ? p_beg + pps : hw;
+    const float km = kmax[(size_t)b * C3 + heads * 32 + head * 32 + r];
+    const float* kb = qkv + (size_t)b * hw * C3 + heads * 32 + head * 32 + r;
+    const float* vb = kb + heads * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float z = 0.f;
+    constexpr int U = 8;
+    for (long long p = p_beg; p < p_end; p += 2 * U) {
+        float kv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pix = p + 2 * u + kk;
+            const bool ok = pix < p_end;
+            kv[u] = ok ? kb[(size_t)pix * C3] : -INFINITY;
+            vv[u] = ok ? vb[(size_t)pix * C3] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float e = __expf(kv[u] - km);                // exp(-inf) = 0 for masked pixels
+            z += e;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e, vv[u], acc, 0, 0, 0);
+        }
+    }
+    z += __shfl_xor(z, 32);
+    float* cp = part + (size_t)gid * (1024 + 32);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cp[acc_row(i, kk) * 32 + r] = acc[i];
+    if (kk == 0) cp[1024 + r] = z;
+}
+
+// pass 1 finalize: ctx[b][head][d][e] = sum_s ctx_p / (sum_s z_p[d] * hw)   (v / (h*w), :204)
+__global__ __launch_bounds__(256) void linattn_ctx_finalize_kernel(const float* __restrict__ part, int heads, int S,
+                                                                   long long hw, float* __restrict__ ctx) {
+    const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int d = i >> 5;
+        float c = 0.f, z = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float* cp = part + ((size_t)((size_t)b * S + s) * heads + head) * (1024 + 32);
+            c += cp[i];
+            z += cp[1024 + d];
+        }
+        ctx[(size_t)blockIdx.x * 1024 + i] = c / (z * (float)hw);
+    }
+}
+
+// linear attention, pass 2: o[n][head*32+e] = sum_d ctx[d][e] * softmax_d(q[n][:])[d] * 32^-0.5
+// O^T[e][pixel] tile per wave: A = ctx^T (16 VGPRs, resident across pixel tiles), B = q' with one
+// pixel per lane so the softmax over d is lane-local plus one cross-half exchange.
+__global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                          int B, long long hw, int heads, int tpw, float* __restrict__ o) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const long long tiles = (hw + 31) / 32;
+    const long long chunks = (tiles + tpw - 1) / tpw;
+    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= (long long)B * chunks * heads) return;
+    const int head = (int)(gid % heads);
+    const long long ch = (gid / heads) % chunks;
+    const int b = (int)(gid / ((long long)heads * chunks));
+    const int C3 = 3 * heads * 32, CO = heads * 32;
+    float a[16];
+    const float* cb = ctx + ((size_t)b * heads + head) * 1024;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = cb[(8 * (s >> 2) + 4 * hh + (s & 3)) * 32 + r];
+    const float scale = 0.17677669529663688110f;   // 32^-0.5
+    for (long long t = ch * tpw; t < (ch + 1) * tpw && t < tiles; ++t) {
+        const long long p = t * 32 + r;
+        const bool ok = p < hw;
+        float q[16];
+        const float* qp = qkv + ((size_t)b * hw + (ok ? p : 0)) * C3 + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(qp + 4 * (2 * g + hh));
+            q[4 * g] = v.x; q[4 * g + 1] = v.y; q[4 * g + 2] = v.z; q[4 * g + 3] = v.w;
+        }
+        float m = q[0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s) m = fmaxf(m, q[s]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { q[s] = __expf(q[s] - m); sum += q[s]; }
+        sum += __shfl_xor(sum, 32);
+        const float f = scale / sum;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q[s] * f, acc, 0, 0, 0);
+        if (ok) {
+            float* op = o + ((size_t)b * hw + p) * CO + head * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(op + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bottleneck attention (models/unet_model.py:229-241): q,k l2-normalised along the TOKEN axis
+// (inv_norm from the to_qkv epilogue), sim = scale * q^T k, softmax over keys, out = attn v.
+// One wave per (sample, head, 32-query tile); two sweeps over the key tiles (row max, then
+// exp / row sum / PV), S^T[key][query] kept in the accumulator so P feeds the PV MFMA directly.
+__global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ inv,
+                                                        int B, int ntok, int heads, float scale, float* __restrict__ o) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int qtiles = (ntok + 31) / 32;
+    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= (long long)B * qtiles * heads) return;
+    const int head = (int)(gid % heads);
+    const int qt = (int)((gid / heads) % qtiles);
+    const int b = (int)(gid / ((long long)heads * qtiles));
+    const int C3 = 3 * heads * 32, CO = heads * 32;
+    const float* base = qkv + (size_t)b * ntok * C3;
+    const float* ivq = inv + (size_t)b * C3 + head * 32;
+    const float* ivk = ivq + heads * 32;
+
+    const int qi = qt * 32 + r;
+    const bool qok = qi < ntok;
+    float qv[16], ik[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = 4 * (2 * g + hh);
+        const float4 v = *(const float4*)(base + (size_t)(qok ? qi : 0) * C3 + head * 32 + d0);
+        const float4 n = *(const float4*)(ivq + d0);
+        const float4 nk = *(const float4*)(ivk + d0);
+        qv[4 * g] = v.x * n.x * scale; qv[4 * g + 1] = v.y * n.y * scale;
+        qv[4 * g + 2] = v.z * n.z * scale; qv[4 * g + 3] = v.w * n.w * scale;
+        ik[4 * g] = nk.x; ik[4 * g + 1] = nk.y; ik[4 * g + 2] = nk.z; ik[4 * g + 3] = nk.w;
+    }
+    const int ktiles = (ntok + 31) / 32;
+
+    auto scores = [&](int jt, f32x16& st) {
+        const int kj = jt * 32 + r;
+        const bool kok = kj < ntok;
+        float kv[16];
+        const float* kp = base + (size_t)(kok ? kj : 0) * C3 + heads * 32 + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(kp + 4 * (2 * g + hh));
+            kv[4 * g] = kok ? v.x * ik[4 * g] : 0.f; kv[4 * g + 1] = kok ? v.y * ik[4 * g + 1] : 0.f;
+            kv[4 * g + 2] = kok ? v.z * ik[4 * g + 2] : 0.f; kv[4 * g + 3] = kok ? v.w * ik[4 * g + 3] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[s], qv[s], st, 0, 0, 0);
+    };
+
+    float m = -INFINITY;
+    for (int jt = 0; jt < ktiles; ++jt) {
+        f32x16 st;
+        scores(jt, st);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (jt * 32 + acc_row(i, hh) < ntok) m = fmaxf(m, st[i]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+
+    f32x16 oacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+    float l = 0.f;
+    const float* vbase = base + 2 * heads * 32 + head * 32 + r;
+    for (int jt = 0; jt < ktiles; ++jt) {
+        f32x16 st;
+        scores(jt, st);
+        float va[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int j = jt * 32 + acc_row(s, hh);
+            va[s] = j < ntok ? vbase[(size_t)j * C3] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float p = (jt * 32 + acc_row(s, hh) < ntok) ? __expf(st[s] - m) : 0.f;
+            l += p;
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], p, oacc, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32);
+    if (qok) {
+        const float il = 1.f / l;
+        float* op = o + ((size_t)b * ntok + qi) * CO + head * 32 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(op + 8 * g) = make_float4(oacc[4 * g] * il, oacc[4 * g + 1] * il, oacc[4 * g + 2] * il,
+                                                 oacc[4 * g + 3] * il);
+    }
+}
+
+}  // namespace
+
+// pixel splits of the context sweep: enough waves to fill 256 CUs x 4 SIMDs several times over.
+int la_ctx_splits(long long hw) {
+    long long s = hw / 512;
+    if (s < 1) s = 1;
+    if (s > 128) s = 128;
+    return (int)s;
+}
+size_t la_ctx_partial_floats(int B, int heads, long long hw) {
+    return (size_t)B * la_ctx_splits(hw) * heads * (1024 + 32);
+}
+
+int op_linattn_context(const float* qkv, const float* kmax, int B, long long hw, int heads, float* partial,
+                       float* ctx, hipStream_t st) {
+    const int S = la_ctx_splits(hw);
+    long long pps = (hw + S - 1) / S;
+    pps += pps & 1;
+    const long long waves = (long long)B * S * heads;
+    hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, kmax, B, hw, heads,
+                       S, pps, partial);
+    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    return LAUNCH_OK();
+}
+
+int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, hipStream_t st) {
+    const int tpw = 8;
+    const long long tiles = (hw + 31) / 32, chunks = (tiles + tpw - 1) / tpw;
+    const long long waves = (long long)B * chunks * heads;
+    hipLaunchKernelGGL(linattn_out_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, ctx, B, hw, heads,
+                       tpw, o);
+    return LAUNCH_OK();
+}
+
+int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o,
+                      hipStream_t st) {
+    const long long waves = (long long)B * ((ntok + 31) / 32) * heads;
+    hipLaunchKernelGGL(full_attn_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, inv_norm, B, ntok,
+                       heads, scale, o);
+    return LAUNCH_OK();
+}

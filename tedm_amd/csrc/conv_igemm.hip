@@ -1,0 +1,357 @@
+// conv_igemm.hip -- NHWC implicit-GEMM convolution on gfx950 MFMA (v_mfma_f32_32x32x16_bf16).
+//
+// Replaces every nn.Conv2d on the UNet hot path except the 1-channel stem:
+//   Block.proj 3x3            models/unet_model.py:122,127
+//   Downsample 4x4 stride 2   models/unet_model.py:47-49
+//   Upsample nearest x2 + 3x3 models/unet_model.py:39-44   (upsample fused into the halo gather)
+//   last-level 3x3            models/unet_model.py:307-308,323-324
+//   res_conv / to_qkv / to_out 1x1   models/unet_model.py:156-159,185,187-190,221-222
+//
+// GEMM view: D[pixel][cout] = sum_{tap,cin} A[pixel+tap][cin] * W[cout][cin][tap].
+//   * One workgroup (4 waves) owns TR rows x 32 columns of output pixels of one image and
+//     WN*32 output channels.  An MFMA M-tile is one 32-pixel row segment, so the A fragment of
+//     tap (ky,kx) is the same LDS image shifted by a compile-time byte offset.
+//   * Activations stay fp32 in HBM (the 1e-3 eps gate rules out bf16 storage);
+//     while a 16*KS-channel chunk of the haloed input tile is staged into LDS the prologue of
+//     the consumer is applied (GroupNorm-apply+FiLM+SiLU folded to silu(a*x+b), or channel
+//     LayerNorm), the value is split into bf16 hi / bf16 lo planes, and the chunk is double
+//     buffered against the MFMA loop.  LDS pixel stride is (2*KS+1)*16 B: odd multiple of 16 B
+//     => ds_read_b128 of 16 consecutive pixels is bank-conflict free without address math.
+//   * Weights are pre-packed (pack.hip) in MFMA B-fragment order, hi/lo planes, so each wave
+//     fetches its own 32-cout slice straight from L2 with one coalesced 16-B load per lane per
+//     fragment: weights never touch LDS and are never re-read by the same workgroup.
+//   * bf16x3: acc += Ahi*Bhi + Alo*Bhi + Ahi*Blo (fp32 accumulate in the MFMA).
+//   * Epilogue: +bias, optional (GN+SiLU'd) addend for the resnet residual, fp32 NHWC store in
+//     128-B segments, and per-output-channel sum/sumsq (GroupNorm, l2norm) or max (k-softmax)
+//     partials written to a deterministic slab (no atomics).
+#include "common.h"
+#include <string.h>
+#include "../../include/tedm_hip.h"
+
+namespace {
+
+template <int KH, int KW, int STRIDE, int WM, int MT, int KS, int NBUF, int PREC>
+struct Geo {
+    static constexpr int TR = WM * MT;                       // output rows per tile
+    static constexpr int HR = (TR - 1) * STRIDE + KH;        // halo rows / cols
+    static constexpr int HC = 31 * STRIDE + KW;
+    static constexpr int HR2 = (HR + 1) / 2, HC2 = (HC + 1) / 2;
+    static constexpr int PLANE2 = HR2 * HC2;                 // stride-2: one parity plane
+    static constexpr int NPIX = STRIDE == 1 ? HR * HC : 4 * PLANE2;
+    static constexpr int PSTRIDE = KS * 32 + 16;             // bytes / pixel / precision plane
+    static constexpr int REGION = NPIX * PSTRIDE;
+    static constexpr int NPL = PREC == TEDM_PREC_BF16X3 ? 2 : 1;
+    static constexpr int BUFSZ = REGION * NPL;
+    static constexpr int LDS = BUFSZ * NBUF;
+    static constexpr int PIECES = HR * HC * 2 * KS;          // (halo pixel, 8-channel piece)
+    static constexpr int NIT = (PIECES + 255) / 256;
+};
+
+template <int KH, int KW, int STRIDE, int PAD, int UPS, int WM, int WN, int MT, int KS, int NBUF,
+          int PRO, int PREC>
+__global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_kernel(ConvArgs a) {
+    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC>;
+    constexpr int T = KH * KW;
+    constexpr int NPL = G::NPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int tile = blockIdx.x;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int n = tile / tpi;
+    tile -= n * tpi;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * G::TR, ox0 = tx * 32;
+    const int CT = (a.Cout + 31) >> 5;
+    const int ct = blockIdx.y * WN + wn;
+    const bool active = ct < CT;                              // wave-uniform
+    const int Cin = a.C1 + a.C2;
+    const int Hin = UPS ? a.H * 2 : a.H, Win = UPS ? a.W * 2 : a.W;
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+
+    // ---- per-thread staging geometry (identical for every channel chunk) ----------------
+    int gp[G::NIT];        // source pixel index (n*H+sy)*W+sx, -1 = zero padding, -2 = no piece
+    int lofs[G::NIT];      // LDS byte offset of this piece inside a precision plane
+    float ln_r[G::NIT], ln_m[G::NIT];
+    const int piece = tid % (2 * KS);
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int i = tid + it * 256;
+        const int pl = i / (2 * KS);
+        gp[it] = -2; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
+        if (pl < G::HR * G::HC) {
+            const int hy = pl / G::HC, hx = pl - hy * G::HC;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+            gp[it] = valid ? (n * a.H + sy) * a.W + sx : -1;
+            const int lpix = STRIDE == 1 ? pl
+                : ((hy & 1) * 2 + (hx & 1)) * G::PLANE2 + (hy >> 1) * G::HC2 + (hx >> 1);
+            lofs[it] = lpix * G::PSTRIDE + piece * 16;
+            if (PRO == PRO_LN && valid) {
+                const float2 s = *(const float2*)(a.pro_b + (size_t)gp[it] * 2);
+                ln_r[it] = s.x; ln_m[it] = s.y;
+            }
+        }
+    }
+
+    float raw[G::NIT][8];
+    float pa[8], pb[8];
+
+    auto issue_loads = [&](int c) {
+        const int cb = c * (16 * KS) + piece * 8;             // channel in the virtual concat
+        const float* src; int cs, ch;
+        if (cb < a.C1) { src = a.x1; cs = a.C1; ch = cb; }
+        else           { src = a.x2; cs = a.C2; ch = cb - a.C1; }
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            if (gp[it] >= 0) {
+                const float4* p = (const float4*)(src + (size_t)gp[it] * cs + ch);
+                const float4 v0 = p[0], v1 = p[1];
+                raw[it][0] = v0.x; raw[it][1] = v0.y; raw[it][2] = v0.z; raw[it][3] = v0.w;
+                raw[it][4] = v1.x; raw[it][5] = v1.y; raw[it][6] = v1.z; raw[it][7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[it][j] = 0.f;
+            }
+        }
+        if (PRO == PRO_GN) {
+            const float4* qa = (const float4*)(a.pro_a + (size_t)n * Cin + cb);
+            const float4* qb = (const float4*)(a.pro_b + (size_t)n * Cin + cb);
+            const float4 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
+            pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w;
+            pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+            pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w;
+            pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+        } else if (PRO == PRO_LN) {
+            const float4* qa = (const float4*)(a.pro_a + cb);
+            const float4 a0 = qa[0], a1 = qa[1];
+            pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w;
+            pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+        }
+    };
+
+    auto write_lds = [&](int buf) {
+        char* base = smem + buf * G::BUFSZ;
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            if (gp[it] == -2) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = raw[it][j];
+                if (gp[it] >= 0) {
+                    if (PRO == PRO_GN) x = silu_f(fmaf(pa[j], x, pb[j]));
+                    else if (PRO == PRO_LN) x = pa[j] * (x * ln_r[it] - ln_m[it]);
+                }
+                v[j] = x;
+            }
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *(uint4*)(base + lofs[it]) = hi;
+            if (NPL == 2) *(uint4*)(base + G::REGION + lofs[it]) = lo;
+        }
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    const uint4* wq = (const uint4*)a.wpk;
+    const int lane_a = (STRIDE == 1 ? (wm * MT * G::HC + r) : (wm * MT * G::HC2 + r)) * G::PSTRIDE + h * 16;
+
+    auto compute = [&](int c, int buf) {
+        if (!active) return;
+        const char* sb = smem + buf * G::BUFSZ + lane_a;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            uint4 bq[KW][KS][NPL];
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p)
+                        bq[kx][ks][p] = wq[((((size_t)ct * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];  // packed layout always carries hi,lo
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[kx][ks][0]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int poff = STRIDE == 1
+                            ? ((mt + ky) * G::HC + kx)
+                            : (((ky & 1) * 2 + (kx & 1)) * G::PLANE2 + (mt + (ky >> 1)) * G::HC2 + (kx >> 1));
+                        const int off = poff * G::PSTRIDE + ks * 32;
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off));
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
+                        if (NPL == 2) {
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off + G::REGION));
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[kx][ks][NPL - 1]);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+        }
+    };
+
+    const int NC = a.nk16 / KS;
+    if (NBUF == 2) {
+        issue_loads(0);
+        write_lds(0);
+        __syncthreads();
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) issue_loads(c + 1);
+            compute(c, c & 1);
+            if (c + 1 < NC) write_lds((c + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < NC; ++c) {
+            issue_loads(c);
+            __syncthreads();
+            write_lds(0);
+            __syncthreads();
+            compute(c, 0);
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------
+    if (!active) return;
+    const int cout = ct * 32 + r;
+    const bool cok = cout < a.Cout;
+    const float bias = (a.bias && cok) ? a.bias[cout] : 0.f;
+    float aa = 1.f, ab = 0.f;
+    if (a.add_a && cok) { aa = a.add_a[(size_t)n * a.Cout + cout]; ab = a.add_b[(size_t)n * a.Cout + cout]; }
+    float s1 = 0.f, s2 = 0.f, smax = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int oy = oy0 + wm * MT + mt;
+        if (oy >= a.Ho) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (ox < a.Wo && cok) {
+                const size_t o = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + cout;
+                float v = acc[mt][i] + bias;
+                if (a.add) {
+                    float t = a.add[o];
+                    if (a.add_a) t = silu_f(fmaf(aa, t, ab));
+                    v += t;
+                }
+                a.out[o] = v;
+                s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+            }
+        }
+    }
+    if (a.stats_mode != STATS_NONE) {
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); smax = fmaxf(smax, __shfl_xor(smax, 32));
+        if (h == 0 && cok) {
+            const int E = tpi * WM;
+            const int e = (ty * a.tiles_x + tx) * WM + wm;
+            if (a.stats_mode == STATS_SUMSQ) {
+                float2* p = (float2*)a.stats + ((size_t)n * E + e) * a.Cout + cout;
+                *p = make_float2(s1, s2);
+            } else {
+                a.stats[((size_t)n * E + e) * a.Cout + cout] = smax;
+            }
+        }
+    }
+}
+
+struct TileSel { int wm, wn, mt; };
+
+// Tile shapes (rows = wm*mt, always 32 columns, wn*32 output channels):
+//   id 0 "wide8"  : 1x4 waves, 8 M-tiles -> 256 px x 128 cout, 1 wave/SIMD (uses >256 VGPRs)
+//   id 1 "narrow" : 2x2 waves, 4 M-tiles -> 256 px x  64 cout
+//   id 2 "wide4"  : 1x4 waves, 4 M-tiles -> 128 px x 128 cout
+// stride-2 convs use half the rows (the halo doubles).
+int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
+
+inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : 1; }
+inline TileSel tile_geom(int id, int stride) {
+    TileSel t = id == 0 ? TileSel{1, 4, 8} : id == 1 ? TileSel{2, 2, 4} : TileSel{1, 4, 4};
+    if (stride == 2) t.mt = t.mt > 2 ? t.mt / 2 : t.mt;
+    return t;
+}
+
+template <int KH, int KW, int STRIDE, int PAD, int UPS, int WM, int WN, int MT, int KS, int NBUF, int PRO, int PREC>
+int launch_one(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC>;
+    auto kern = conv_igemm_kernel<KH, KW, STRIDE, PAD, UPS, WM, WN, MT, KS, NBUF, PRO, PREC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+            return TEDM_EHIP;
+        attr_set = true;
+    }
+    const int CT = (a.Cout + 31) / 32;
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, (CT + WN - 1) / WN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, st, a);
+    return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+}
+
+template <int KH, int KW, int STRIDE, int PAD, int UPS, int KS, int NBUF, int PRO, int PREC>
+int launch_tile(const ConvArgs& a, int tile_id, hipStream_t st) {
+    constexpr int D = STRIDE == 2 ? 2 : 1;
+    switch (tile_id) {
+        case 0:  return launch_one<KH, KW, STRIDE, PAD, UPS, 1, 4, 8 / D, KS, NBUF, PRO, PREC>(a, st);
+        case 1:  return launch_one<KH, KW, STRIDE, PAD, UPS, 2, 2, 4 / D, KS, NBUF, PRO, PREC>(a, st);
+        default: return launch_one<KH, KW, STRIDE, PAD, UPS, 1, 4, 4 / D, KS, NBUF, PRO, PREC>(a, st);
+    }
+}
+
+template <int PREC>
+int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st) {
+    if (KH == 3 && stride == 1 && !ups && pro == PRO_NONE) return launch_tile<3, 3, 1, 1, 0, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
+    if (KH == 3 && stride == 1 && !ups && pro == PRO_GN)   return launch_tile<3, 3, 1, 1, 0, 1, 2, PRO_GN, PREC>(a, tile_id, st);
+    if (KH == 3 && stride == 1 && ups && pro == PRO_NONE)  return launch_tile<3, 3, 1, 1, 1, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
+    if (KH == 4 && stride == 2 && !ups && pro == PRO_NONE) return launch_tile<4, 4, 2, 1, 0, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
+    if (KH == 1 && stride == 1 && !ups) {
+        if (pro == PRO_NONE) return launch_tile<1, 1, 1, 0, 0, 2, 1, PRO_NONE, PREC>(a, tile_id, st);
+        if (pro == PRO_LN)   return launch_tile<1, 1, 1, 0, 0, 2, 1, PRO_LN, PREC>(a, tile_id, st);
+    }
+    return TEDM_EINVAL;
+}
+
+}  // namespace
+
+int conv_set_tuning(const char* key, int v) {
+    if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 2) { g_tile_wide = v; return TEDM_OK; }
+    return TEDM_EINVAL;
+}
+
+int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {
+    (void)KH;
+    const TileSel t = tile_geom(select_tile_id(Cout), stride);
+    const int TR = t.wm * t.mt;
+    return ((Ho + TR - 1) / TR) * ((Wo + 31) / 32) * t.wm;
+}
+
+size_t conv_packed_bytes(int Cout, int Cin, int taps) {
+    const size_t CT = (Cout + 31) / 32;
+    return CT * (size_t)(Cin / 16) * taps * 2 /*hi,lo*/ * 1024;
+}
+
+// a.tiles_x / a.tiles_y / a.nk16 are filled here.
+int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipStream_t st) {
+    ConvArgs a = a_in;
+    const int Cin = a.C1 + a.C2;
+    if (Cin % 16 || a.C1 % 16 || (a.x2 && a.C2 % 16)) return TEDM_EINVAL;
+    if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
+    const int tile_id = select_tile_id(a.Cout);
+    const TileSel t = tile_geom(tile_id, stride);
+    const int TR = t.wm * t.mt;
+    a.tiles_y = (a.Ho + TR - 1) / TR;
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.nk16 = Cin / 16;
+    if (a.prec == TEDM_PREC_BF16) return launch_prec<TEDM_PREC_BF16>(a, KH, stride, ups, pro, tile_id, st);
+    return launch_prec<TEDM_PREC_BF16X3>(a, KH, stride, ups, pro, tile_id, st);
+}

@@ -1,0 +1,513 @@
+// elementwise.hip -- the HBM-bound fp32 kernels around the MFMA convolutions (all NHWC):
+//   q-sample, 7x7 stem, time-embedding MLP + fused FiLM projections, GroupNorm finalize,
+//   resnet-block output (GN-apply + SiLU + residual [+ channel-LayerNorm stats]), channel
+//   LayerNorm (+ residual), final 1x1 conv, per-channel norm / max finalizers, tap -> features.
+// Per-pixel reductions use wave64 xor-shuffles over the lanes that share a pixel.
+#include "common.h"
+#include "ops.h"
+#include "../../include/tedm_hip.h"
+
+namespace {
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP)
+
+// ---------------------------------------------------------------------------------------
+// q-sample: models/diffusion_model.py:176-203 (+ :169-170 normalisation)
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                const long long* __restrict__ t, const float* __restrict__ ca,
+                                const float* __restrict__ cb, int T, float* __restrict__ xt,
+                                long long chw, long long total, int normalize) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / chw);
+        long long ti = t[b];
+        ti = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
+        float x = x0[i];
+        if (normalize) x = x * 2.f - 1.f;
+        xt[i] = ca[ti] * x + cb[ti] * noise[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stem: Conv2d(channels, init_dim, 7, padding=3), models/unet_model.py:267,334.
+// NCHW input (channels is 1 for TEDM) -> NHWC output.  One thread per output pixel, 64 output
+// channels per pass in registers; weights [ci][tap][co] and the haloed input tile live in LDS
+// (weight reads are wave-wide broadcasts).
+constexpr int STEM_TR = 8, STEM_TC = 32, STEM_HR = STEM_TR + 6, STEM_HC = STEM_TC + 6;
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int B, int Cin, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sx = (float*)smem;                               // [Cin][HR][HC]
+    float* sw = sx + ((Cin * STEM_HR * STEM_HC + 3) & ~3);  // [Cin*49][64]
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
+    int tile = blockIdx.x;
+    const int n = tile / (tiles_x * tiles_y);
+    tile -= n * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * STEM_TR, ox0 = tx * STEM_TC;
+    for (int i = tid; i < Cin * STEM_HR * STEM_HC; i += 256) {
+        const int ci = i / (STEM_HR * STEM_HC);
+        const int rem = i - ci * STEM_HR * STEM_HC;
+        const int hy = rem / STEM_HC, hx = rem - hy * STEM_HC;
+        const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+        sx[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((size_t)(n * Cin + ci) * H + iy) * W + ix] : 0.f;
+    }
+    const int py = tid / STEM_TC, px = tid % STEM_TC;
+    const int oy = oy0 + py, ox = ox0 + px;
+    for (int cb = 0; cb < Cout; cb += 64) {
+        __syncthreads();
+        for (int i = tid; i < Cin * 49 * 64; i += 256) {
+            const int co = i & 63, k = i >> 6;              // k = ci*49 + tap
+            sw[i] = (cb + co < Cout) ? w[(size_t)(cb + co) * Cin * 49 + k] : 0.f;
+        }
+        __syncthreads();
+        float acc[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) acc[j] = 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const float xv = sx[(ci * STEM_HR + py + ky) * STEM_HC + px + kx];
+                    const float4* wr = (const float4*)(sw + (size_t)((ci * 7 + ky) * 7 + kx) * 64);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float4 wv = wr[q];
+                        acc[4 * q + 0] = fmaf(xv, wv.x, acc[4 * q + 0]);
+                        acc[4 * q + 1] = fmaf(xv, wv.y, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(xv, wv.z, acc[4 * q + 2]);
+                        acc[4 * q + 3] = fmaf(xv, wv.w, acc[4 * q + 3]);
+                    }
+                }
+        if (oy < H && ox < W) {
+            float* o = out + ((size_t)(n * H + oy) * W + ox) * Cout + cb;
+            if (cb + 64 <= Cout && (Cout & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 bv = *(const float4*)(bias + cb + 4 * q);
+                    *(float4*)(o + 4 * q) = make_float4(acc[4 * q] + bv.x, acc[4 * q + 1] + bv.y,
+                                                        acc[4 * q + 2] + bv.z, acc[4 * q + 3] + bv.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 64; ++j)
+                    if (cb + j < Cout) o[j] = acc[j] + bias[cb + j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// time MLP: SinusoidalPosEmb -> Linear -> GELU(erf) -> Linear (models/unet_model.py:76-93,287-292)
+// followed by the SiLU every ResnetBlock.time_mlp applies first (:149-152).  One block per sample.
+// freqs[half] is bound by the host (computed exactly as the reference does, on the CPU).
+__global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   int dim, int tdim, float* __restrict__ st /*[B][tdim]*/) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* emb = (float*)smem;         // [dim]
+    float* hid = emb + dim;            // [tdim]
+    const int b = blockIdx.x, half = dim / 2;
+    const float tv = t[b];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float a = tv * freqs[i];
+        emb[i] = sinf(a);
+        emb[half + i] = cosf(a);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
+        float s = b1[j];
+        for (int k = 0; k < dim; ++k) s = fmaf(w1[(size_t)j * dim + k], emb[k], s);
+        hid[j] = 0.5f * s * (1.f + erff(s * 0.70710678118654752440f));
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
+        float s = b2[j];
+        for (int k = 0; k < tdim; ++k) s = fmaf(w2[(size_t)j * tdim + k], hid[k], s);
+        st[(size_t)b * tdim + j] = silu_f(s);
+    }
+}
+
+// All ResnetBlock.time_mlp Linear(tdim -> 2*Cout) projections as ONE skinny GEMM over the
+// concatenated weight (J rows): film[b][j] = wf[j] . st[b] + bf[j].  One wave per output row.
+__global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ st, const float* __restrict__ wf,
+                                                   const float* __restrict__ bf, int B, int tdim, int J,
+                                                   float* __restrict__ film) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= J) return;
+    const float bj = bf[j];
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+        for (int k = lane; k < tdim; k += 64) s = fmaf(wf[(size_t)j * tdim + k], st[(size_t)b * tdim + k], s);
+        s = wave_sum(s);
+        if (lane == 0) film[(size_t)b * J + j] = s + bj;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm finalize (nn.GroupNorm(groups, C, eps=1e-5), models/unet_model.py:123,128):
+// reduce the conv epilogue's per-channel (sum, sumsq) slab in fp64, then fold normalisation,
+// affine and the optional FiLM (x*(scale+1)+shift, :132) into per-(sample, channel) a, b so the
+// consumer computes silu(a*x + b).   One block per (sample, group).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ slab, int E, int C, int groups,
+                                                          long long hw, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ film, int film_stride,
+                                                          float* __restrict__ oa, float* __restrict__ ob) {
+    __shared__ double r1[256], r2[256];
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int cg = C / groups;
+    double s1 = 0.0, s2 = 0.0;
+    const int total = E * cg;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int e = i / cg, c = g * cg + (i - e * cg);
+        const float2 v = *(const float2*)(slab + (((size_t)n * E + e) * C + c) * 2);
+        s1 += v.x; s2 += v.y;
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    const double cnt = (double)hw * cg;
+    const double mean = r1[0] / cnt;
+    double var = r2[0] / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float meanf = (float)mean;
+    for (int i = threadIdx.x; i < cg; i += 256) {
+        const int c = g * cg + i;
+        float a = rstd * gamma[c];
+        float b = beta[c] - meanf * a;
+        if (film) {
+            const float sc = film[(size_t)n * film_stride + c] + 1.f;
+            const float sh = film[(size_t)n * film_stride + C + c];
+            a *= sc;
+            b = b * sc + sh;
+        }
+        oa[(size_t)n * C + c] = a;
+        ob[(size_t)n * C + c] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pixel-vector kernels: a pixel's C channels are spread over LPP lanes (LPP power of two <= 64),
+// V float4 per lane; 64/LPP pixels per wave.
+struct PixMap { int lpp, v; };
+
+template <int V>
+__global__ __launch_bounds__(256) void resblock_out_kernel(const float* __restrict__ y, const float* __restrict__ ga,
+                                                           const float* __restrict__ gb, const float* __restrict__ x,
+                                                           float* __restrict__ out, float* __restrict__ lnstats,
+                                                           long long P, long long hw, int C, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        const int n = ok ? (int)(p / hw) : 0;
+        float4 val[V];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = (v * lpp + q) * 4;
+            val[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float4 yy = *(const float4*)(y + (size_t)p * C + c);
+                const float4 aa = *(const float4*)(ga + (size_t)n * C + c);
+                const float4 bb = *(const float4*)(gb + (size_t)n * C + c);
+                const float4 xx = *(const float4*)(x + (size_t)p * C + c);
+                val[v].x = silu_f(fmaf(aa.x, yy.x, bb.x)) + xx.x;
+                val[v].y = silu_f(fmaf(aa.y, yy.y, bb.y)) + xx.y;
+                val[v].z = silu_f(fmaf(aa.z, yy.z, bb.z)) + xx.z;
+                val[v].w = silu_f(fmaf(aa.w, yy.w, bb.w)) + xx.w;
+                *(float4*)(out + (size_t)p * C + c) = val[v];
+            }
+            s += (val[v].x + val[v].y) + (val[v].z + val[v].w);
+        }
+        if (lnstats) {                                         // uniform branch
+            const float mean = group_sum(s, lpp) / (float)C;
+            float d2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float dx = val[v].x - mean, dy = val[v].y - mean, dz = val[v].z - mean, dw = val[v].w - mean;
+                d2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float var = group_sum(d2, lpp) / (float)C;
+            const float rstd = rsqrtf(var + 1e-5f);
+            if (ok && q == 0) *(float2*)(lnstats + (size_t)p * 2) = make_float2(rstd, mean * rstd);
+        }
+    }
+}
+
+// channel-LayerNorm statistics only (models/unet_model.py:52-61): stats[p] = (rstd, mean*rstd)
+template <int V>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ lnstats,
+                                                       long long P, int C, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        float4 val[V];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            val[v] = ok ? *(const float4*)(x + (size_t)p * C + (v * lpp + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (val[v].x + val[v].y) + (val[v].z + val[v].w);
+        }
+        const float mean = group_sum(s, lpp) / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float dx = val[v].x - mean, dy = val[v].y - mean, dz = val[v].z - mean, dw = val[v].w - mean;
+            d2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = rsqrtf(group_sum(d2, lpp) / (float)C + 1e-5f);
+        if (ok && q == 0) *(float2*)(lnstats + (size_t)p * 2) = make_float2(rstd, mean * rstd);
+    }
+}
+
+// out = LayerNorm_c(z) * g + x  -- LinearAttention.to_out[1] + Residual (unet_model.py:187-190,36)
+template <int V>
+__global__ __launch_bounds__(256) void ln_res_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                     const float* __restrict__ x, float* __restrict__ out,
+                                                     long long P, int C, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float4 gg[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) gg[v] = *(const float4*)(g + (v * lpp + q) * 4);
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        float4 val[V];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            val[v] = ok ? *(const float4*)(z + (size_t)p * C + (v * lpp + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (val[v].x + val[v].y) + (val[v].z + val[v].w);
+        }
+        const float mean = group_sum(s, lpp) / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float dx = val[v].x - mean, dy = val[v].y - mean, dz = val[v].z - mean, dw = val[v].w - mean;
+            d2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = rsqrtf(group_sum(d2, lpp) / (float)C + 1e-5f);
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const size_t o = (size_t)p * C + (v * lpp + q) * 4;
+                const float4 xx = *(const float4*)(x + o);
+                float4 r;
+                r.x = (val[v].x - mean) * rstd * gg[v].x + xx.x;
+                r.y = (val[v].y - mean) * rstd * gg[v].y + xx.y;
+                r.z = (val[v].z - mean) * rstd * gg[v].z + xx.z;
+                r.w = (val[v].w - mean) * rstd * gg[v].w + xx.w;
+                *(float4*)(out + o) = r;
+            }
+        }
+    }
+}
+
+// final_conv: Conv2d(dim, out_dim, 1) (models/unet_model.py:331,368). NHWC in -> NCHW out.
+template <int V>
+__global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         long long P, long long hw, int C, int OD, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        float4 val[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            val[v] = ok ? *(const float4*)(x + (size_t)p * C + (v * lpp + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 0; o < OD; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float4 ww = *(const float4*)(w + (size_t)o * C + (v * lpp + q) * 4);
+                s = fmaf(val[v].x, ww.x, s); s = fmaf(val[v].y, ww.y, s);
+                s = fmaf(val[v].z, ww.z, s); s = fmaf(val[v].w, ww.w, s);
+            }
+            s = group_sum(s, lpp);
+            if (ok && q == 0) {
+                const long long n = p / hw, pix = p - n * hw;
+                out[((size_t)n * OD + o) * hw + pix] = s + bias[o];
+            }
+        }
+    }
+}
+
+// per-(sample, channel) 1/max(||.||_2 over pixels, 1e-12) from a (sum, sumsq) slab:
+// F.normalize(dim=-1) of models/unet_model.py:23,234.
+__global__ void colnorm_finalize_kernel(const float* __restrict__ slab, int E, int C, int B, float* __restrict__ inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) s += slab[(((size_t)n * E + e) * C + c) * 2 + 1];
+    inv[i] = 1.f / fmaxf((float)sqrt(s), 1e-12f);
+}
+// per-(sample, channel) max over pixels from a max slab (k.softmax(dim=-1) stabiliser, :201)
+__global__ void colmax_finalize_kernel(const float* __restrict__ slab, int E, int C, int B, float* __restrict__ mx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    float m = -INFINITY;
+    for (int e = 0; e < E; ++e) m = fmaxf(m, slab[((size_t)n * E + e) * C + c]);
+    mx[i] = m;
+}
+
+// nearest-resize one NHWC tap to (S,S) and scatter into the NCHW feature tensor
+// (models/datasetDM_model.py:80-83).  F.interpolate(mode='nearest'): src = floor(dst * in/out).
+__global__ void tap_to_features_kernel(const float* __restrict__ tap, int h, int w, int C, float* __restrict__ feats,
+                                       int C_total, int c_off, int S, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % S);
+        long long r = i / S;
+        const int yo = (int)(r % S); r /= S;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        const int ys = (int)(((long long)yo * h) / S), xs = (int)(((long long)xo * w) / S);
+        feats[(((size_t)n * C_total + c_off + c) * S + yo) * S + xo] = tap[(((size_t)n * h + ys) * w + xs) * C + c];
+    }
+}
+
+inline bool pixmap(int C, PixMap& m) {
+    if (C % 4) return false;
+    int v4 = C / 4, lpp = 1;
+    while (lpp < 64 && (v4 % (lpp * 2)) == 0) lpp *= 2;
+    m.lpp = lpp; m.v = v4 / lpp;
+    return m.v >= 1 && m.v <= 4;
+}
+inline unsigned pix_grid(long long P, int lpp) {
+    const long long waves = (P + (64 / lpp) - 1) / (64 / lpp);
+    long long blocks = (waves + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+#define DISPATCH_V(mv, KERN, ...)                                                            \
+    switch (mv) {                                                                              \
+        case 1: hipLaunchKernelGGL(KERN<1>, __VA_ARGS__); break;                               \
+        case 2: hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); break;                               \
+        case 3: hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); break;                               \
+        default: hipLaunchKernelGGL(KERN<4>, __VA_ARGS__); break;                              \
+    }
+
+int op_q_sample(const float* x0, const float* noise, const long long* t, const float* ca, const float* cb, int T,
+                float* xt, int B, long long chw, int normalize, hipStream_t st) {
+    const long long total = (long long)B * chw;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x0, noise, t, ca, cb, T, xt, chw,
+                       total, normalize);
+    return LAUNCH_OK();
+}
+
+int op_stem_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                 int Cout, hipStream_t st) {
+    const size_t lds = (size_t)((Cin * STEM_HR * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 49 * 64 * 4;
+    if (lds > 160 * 1024) return TEDM_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return TEDM_EHIP;
+        attr = true;
+    }
+    const int tiles = ((W + STEM_TC - 1) / STEM_TC) * ((H + STEM_TR - 1) / STEM_TR);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+    return LAUNCH_OK();
+}
+
+int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
+                  const float* b2, int B, int dim, int tdim, float* st_out, hipStream_t st) {
+    hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(256), (size_t)(dim + tdim) * 4, st, t, freqs, w1, b1, w2, b2, dim,
+                       tdim, st_out);
+    return LAUNCH_OK();
+}
+
+int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdim, int J, float* film, hipStream_t st) {
+    if (J <= 0) return TEDM_OK;
+    hipLaunchKernelGGL(film_kernel, dim3((J + 3) / 4), dim3(256), 0, st, st_in, wf, bf, B, tdim, J, film);
+    return LAUNCH_OK();
+}
+
+int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
+                   const float* beta, const float* film, int film_stride, float* oa, float* ob, hipStream_t st) {
+    if (C % groups) return TEDM_EINVAL;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, st, slab, E, C, groups, hw, gamma, beta,
+                       film, film_stride, oa, ob);
+    return LAUNCH_OK();
+}
+
+int op_resblock_out(const float* y, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
+                    int B, long long hw, int C, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    const long long P = (long long)B * hw;
+    DISPATCH_V(m.v, resblock_out_kernel, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, y, ga, gb, x, out, lnstats, P, hw,
+               C, m.lpp);
+    return LAUNCH_OK();
+}
+
+int op_ln_stats(const float* x, float* lnstats, long long P, int C, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    DISPATCH_V(m.v, ln_stats_kernel, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, x, lnstats, P, C, m.lpp);
+    return LAUNCH_OK();
+}
+
+int op_ln_res(const float* z, const float* g, const float* x, float* out, long long P, int C, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    DISPATCH_V(m.v, ln_res_kernel, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, z, g, x, out, P, C, m.lpp);
+    return LAUNCH_OK();
+}
+
+int op_final_conv(const float* x, const float* w, const float* bias, float* out, int B, long long hw, int C, int OD,
+                  hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    const long long P = (long long)B * hw;
+    DISPATCH_V(m.v, final_conv_kernel, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, x, w, bias, out, P, hw, C, OD,
+               m.lpp);
+    return LAUNCH_OK();
+}
+
+int op_colnorm_finalize(const float* slab, int E, int C, int B, float* inv, hipStream_t st) {
+    hipLaunchKernelGGL(colnorm_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, slab, E, C, B, inv);
+    return LAUNCH_OK();
+}
+int op_colmax_finalize(const float* slab, int E, int C, int B, float* mx, hipStream_t st) {
+    hipLaunchKernelGGL(colmax_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, slab, E, C, B, mx);
+    return LAUNCH_OK();
+}
+
+int op_tap_to_features(const float* tap, int B, int h, int w, int C, float* feats, int C_total, int c_off, int S,
+                       hipStream_t st) {
+    const long long total = (long long)B * C * S * S;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(tap_to_features_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tap, h, w, C, feats, C_total,
+                       c_off, S, total);
+    return LAUNCH_OK();
+}

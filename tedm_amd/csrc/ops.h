@@ -1,0 +1,35 @@
+// Host-side launchers of the non-conv kernels (elementwise.hip, attention.hip).  All tensors are
+// fp32, device resident, NHWC unless stated; every launcher enqueues on `st` and returns TEDM_*.
+#pragma once
+#include <hip/hip_runtime.h>
+
+int op_q_sample(const float* x0, const float* noise, const long long* t, const float* ca, const float* cb, int T,
+                float* xt, int B, long long chw, int normalize, hipStream_t st);
+int op_stem_conv(const float* x_nchw, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                 int Cout, hipStream_t st);
+int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
+                  const float* b2, int B, int dim, int tdim, float* st_out, hipStream_t st);
+int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdim, int J, float* film, hipStream_t st);
+int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
+                   const float* beta, const float* film, int film_stride, float* oa, float* ob, hipStream_t st);
+int op_resblock_out(const float* y, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
+                    int B, long long hw, int C, hipStream_t st);
+int op_ln_stats(const float* x, float* lnstats, long long P, int C, hipStream_t st);
+int op_ln_res(const float* z, const float* g, const float* x, float* out, long long P, int C, hipStream_t st);
+int op_final_conv(const float* x, const float* w, const float* bias, float* out_nchw, int B, long long hw, int C,
+                  int OD, hipStream_t st);
+int op_colnorm_finalize(const float* slab, int E, int C, int B, float* inv, hipStream_t st);
+int op_colmax_finalize(const float* slab, int E, int C, int B, float* mx, hipStream_t st);
+int op_tap_to_features(const float* tap, int B, int h, int w, int C, float* feats_nchw, int C_total, int c_off, int S,
+                       hipStream_t st);
+
+// attention.hip  (qkv: (B, hw, 3*heads*32) fp32 with channel order [q | k | v], head-major inside each)
+int la_ctx_splits(long long hw);
+size_t la_ctx_partial_floats(int B, int heads, long long hw);
+int op_linattn_context(const float* qkv, const float* kmax, int B, long long hw, int heads, float* partial,
+                       float* ctx, hipStream_t st);
+int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, hipStream_t st);
+int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o,
+                      hipStream_t st);
+
+int conv_set_tuning(const char* key, int v);

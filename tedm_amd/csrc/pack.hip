@@ -1,0 +1,58 @@
+// pack.hip -- one-time (per weight update) repacking of reference-layout fp32 parameters into the
+// layouts the kernels consume.  Reference layouts: nn.Conv2d OIHW, nn.Linear (out,in)
+// (models/unet_model.py state_dict).
+#include "common.h"
+#include "../../include/tedm_hip.h"
+
+namespace {
+
+// Conv weights -> MFMA B-fragment order for v_mfma_f32_32x32x16_bf16, bf16 hi/lo planes:
+//   wpk[ct][k16][tap][plane][lane][j],  lane = (h<<5)|r :  W[cout = ct*32+r][cin = k16*16+8h+j][tap]
+// (B[k = 8h+j][col = r], cdna guide section 3).  One 16-byte store per (fragment, lane, plane).
+__global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int T, uint4* __restrict__ wpk,
+                                 long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int tap = (int)(f % T); f /= T;
+    const int nk16 = Cin / 16;
+    const int k16 = (int)(f % nk16);
+    const int ct = (int)(f / nk16);
+    const int r = lane & 31, h = lane >> 5;
+    const int cout = ct * 32 + r;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cin = k16 * 16 + 8 * h + j;
+        v[j] = cout < Cout ? w[((size_t)cout * Cin + cin) * T + tap] : 0.f;
+    }
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    const size_t o = (((size_t)ct * nk16 + k16) * T + tap) * 2;
+    wpk[(o + 0) * 64 + lane] = hi;
+    wpk[(o + 1) * 64 + lane] = lo;
+}
+
+__global__ void copy_kernel(const float* __restrict__ s, float* __restrict__ d, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+
+}  // namespace
+
+int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, hipStream_t st) {
+    if (Cin % 16) return TEDM_EINVAL;
+    const int T = KH * KW;
+    const long long CT = (Cout + 31) / 32;
+    const long long total = CT * (Cin / 16) * T * 64;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       w, Cout, Cin, T, (uint4*)wpk, total);
+    return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+}
+
+int copy_rows(const float* src, float* dst, long long n, hipStream_t st) {
+    if (n <= 0) return TEDM_OK;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+}

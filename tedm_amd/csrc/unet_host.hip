@@ -1,0 +1,610 @@
+// unet_host.hip -- host side of libtedm_hip.so: layer plan, parameter binding, weight packing,
+// workspace arena and the kernel sequence of Unet.forward (models/unet_model.py:333-368), all
+// enqueued on the caller's stream.  C ABI: include/tedm_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tedm_hip.h"
+#include "../../include/tedm_hip_ops.h"
+#include "common.h"
+#include "ops.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define CHECK(expr)                                                                         \
+    do {                                                                                    \
+        int _rc = (expr);                                                                   \
+        if (_rc != TEDM_OK) {                                                               \
+            if (!g_err[0]) snprintf(g_err, sizeof(g_err), "%s failed (%d) at %s:%d", #expr, _rc, __FILE__, __LINE__); \
+            return _rc;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+struct Param { std::string key; long long numel; const float* ptr; };
+
+struct ConvW {           // one conv weight in packed MFMA-fragment form (handle-owned)
+    std::string key;     // '<prefix>.weight' ; bias is '<prefix>.bias' when has_bias
+    int cout = 0, cin = 0, k = 0;
+    bool has_bias = true;
+    void* wpk = nullptr;
+    size_t bytes = 0;
+};
+struct ResPlan { std::string pre; int cin = 0, cout = 0; bool has_res = false; int film_off = 0; ConvW c1, c2, res; };
+struct AttnPlan { std::string pre; int C = 0; bool linear = true; ConvW qkv, out; };
+struct LevelPlan { ResPlan b1, b2; AttnPlan attn; ConvW tail; int tail_kind = 0; };   // 0: 4x4 s2, 1: 3x3, 2: up x2 + 3x3
+
+// First-fit arena over the caller's workspace.  dry == true only computes the peak.
+struct Arena {
+    char* base = nullptr; size_t cap = 0; bool dry = true; bool keep = false;
+    size_t top = 0, peak = 0;
+    std::map<size_t, size_t> free_blocks;   // offset -> size
+    std::map<size_t, size_t> live;          // offset -> size
+    bool oom = false;
+    static size_t align(size_t n) { return (n + 255) & ~(size_t)255; }
+    float* alloc(size_t floats) {
+        const size_t n = align(floats * 4 ? floats * 4 : 4);
+        size_t off = (size_t)-1;
+        for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it) {
+            if (it->second >= n) {
+                off = it->first;
+                const size_t rest = it->second - n;
+                free_blocks.erase(it);
+                if (rest) free_blocks[off + n] = rest;
+                break;
+            }
+        }
+        if (off == (size_t)-1) { off = top; top += n; if (top > peak) peak = top; }
+        live[off] = n;
+        if (!dry && off + n > cap) oom = true;
+        return (float*)(base + off);
+    }
+    void release(const void* p) {
+        if (keep || !p) return;
+        const size_t off = (size_t)((const char*)p - base);
+        auto it = live.find(off);
+        if (it == live.end()) return;          // not arena-owned (e.g. caller's feat_out buffer)
+        size_t n = it->second;
+        live.erase(it);
+        size_t o = off;
+        auto nx = free_blocks.find(o + n);
+        if (nx != free_blocks.end()) { n += nx->second; free_blocks.erase(nx); }
+        auto pv = free_blocks.lower_bound(o);
+        if (pv != free_blocks.begin()) {
+            --pv;
+            if (pv->first + pv->second == o) { o = pv->first; n += pv->second; free_blocks.erase(pv); }
+        }
+        if (o + n == top) top = o; else free_blocks[o] = n;
+    }
+};
+
+struct Trace { std::string name; size_t off; int shape[4]; };
+
+}  // namespace
+
+struct tedm_unet {
+    tedm_unet_cfg cfg;
+    int init_dim = 0, out_dim = 0, tdim = 0, nres = 0, hidden = 0;
+    std::vector<int> dims;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<LevelPlan> downs, ups;
+    ResPlan mid1, mid2, fin;
+    AttnPlan mid_attn;
+    std::vector<ConvW*> convs;
+    std::vector<ResPlan*> resblocks;
+    int film_J = 0;
+    float* film_w = nullptr;   // [J][tdim]
+    float* film_b = nullptr;   // [J]
+    bool packed = false;
+    std::vector<Trace> trace;
+
+    ~tedm_unet() {
+        for (ConvW* c : convs) if (c->wpk) (void)hipFree(c->wpk);
+        if (film_w) (void)hipFree(film_w);
+        if (film_b) (void)hipFree(film_b);
+    }
+    void add_param(const std::string& key, long long numel) {
+        index[key] = (int)params.size();
+        params.push_back({key, numel, nullptr});
+    }
+    const float* P(const std::string& key) const {
+        auto it = index.find(key);
+        return it == index.end() ? nullptr : params[it->second].ptr;
+    }
+    void add_conv(ConvW& c, const std::string& pre, int cout, int cin, int k, bool bias) {
+        c.key = pre; c.cout = cout; c.cin = cin; c.k = k; c.has_bias = bias;
+        add_param(pre + ".weight", (long long)cout * cin * k * k);
+        if (bias) add_param(pre + ".bias", cout);
+        convs.push_back(&c);
+    }
+    void add_res(ResPlan& r, const std::string& pre, int cin, int cout) {
+        r.pre = pre; r.cin = cin; r.cout = cout; r.has_res = cin != cout;
+        r.film_off = film_J; film_J += 2 * cout;
+        add_param(pre + ".time_mlp.1.weight", (long long)2 * cout * tdim);
+        add_param(pre + ".time_mlp.1.bias", 2 * cout);
+        add_conv(r.c1, pre + ".block1.proj", cout, cin, 3, true);
+        add_param(pre + ".block1.norm.weight", cout);
+        add_param(pre + ".block1.norm.bias", cout);
+        add_conv(r.c2, pre + ".block2.proj", cout, cout, 3, true);
+        add_param(pre + ".block2.norm.weight", cout);
+        add_param(pre + ".block2.norm.bias", cout);
+        if (r.has_res) add_conv(r.res, pre + ".res_conv", cout, cin, 1, true);
+        resblocks.push_back(&r);
+    }
+    void add_attn(AttnPlan& a, const std::string& pre, int C, bool linear) {
+        a.pre = pre; a.C = C; a.linear = linear;
+        add_conv(a.qkv, pre + ".fn.fn.to_qkv", 3 * hidden, C, 1, false);
+        if (linear) {
+            add_conv(a.out, pre + ".fn.fn.to_out.0", C, hidden, 1, true);
+            add_param(pre + ".fn.fn.to_out.1.g", C);
+        } else {
+            add_conv(a.out, pre + ".fn.fn.to_out", C, hidden, 1, true);
+        }
+        add_param(pre + ".fn.norm.g", C);
+    }
+};
+
+namespace {
+
+int build_plan(tedm_unet* u) {
+    const tedm_unet_cfg& c = u->cfg;
+    if (c.dim <= 0 || c.dim % 32) return fail(TEDM_EINVAL, "dim must be a positive multiple of 32 (got %d)", c.dim);
+    if (c.n_mults < 1 || c.n_mults > TEDM_MAX_LEVELS) return fail(TEDM_EINVAL, "bad n_mults %d", c.n_mults);
+    if (c.dim_head != 32) return fail(TEDM_EINVAL, "dim_head must be 32 (the reference's fixed value, unet_model.py:180,217)");
+    if (c.heads < 1 || c.heads > 16) return fail(TEDM_EINVAL, "bad heads %d", c.heads);
+    if (c.channels < 1 || c.channels > 16) return fail(TEDM_EINVAL, "channels must be in 1..16");
+    if (c.dim % c.groups) return fail(TEDM_EINVAL, "groups must divide dim");
+    u->init_dim = c.init_dim > 0 ? c.init_dim : c.dim;
+    u->out_dim = c.out_dim > 0 ? c.out_dim : c.channels;
+    if (u->init_dim % 32 || u->init_dim % c.groups) return fail(TEDM_EINVAL, "init_dim must be a multiple of 32 and of groups");
+    u->tdim = c.dim * 4;
+    u->nres = c.n_mults;
+    u->hidden = c.heads * c.dim_head;
+    u->dims.push_back(u->init_dim);
+    for (int i = 0; i < c.n_mults; ++i) {
+        if (c.dim_mults[i] < 1) return fail(TEDM_EINVAL, "bad dim_mult");
+        u->dims.push_back(c.dim * c.dim_mults[i]);
+    }
+    // state-dict order of models/unet_model.py:267-331
+    u->add_param("init_conv.weight", (long long)u->init_dim * c.channels * 49);
+    u->add_param("init_conv.bias", u->init_dim);
+    u->add_param("time_mlp.0.freqs", c.dim / 2);   // facade-bound table (not a reference key)
+    u->add_param("time_mlp.1.weight", (long long)u->tdim * c.dim);
+    u->add_param("time_mlp.1.bias", u->tdim);
+    u->add_param("time_mlp.3.weight", (long long)u->tdim * u->tdim);
+    u->add_param("time_mlp.3.bias", u->tdim);
+    u->downs.resize(u->nres);
+    u->ups.resize(u->nres);
+    for (int i = 0; i < u->nres; ++i) {
+        const int din = u->dims[i], dout = u->dims[i + 1];
+        const bool last = i == u->nres - 1;
+        const std::string pre = "downs." + std::to_string(i);
+        LevelPlan& L = u->downs[i];
+        u->add_res(L.b1, pre + ".0", din, din);
+        u->add_res(L.b2, pre + ".1", din, din);
+        u->add_attn(L.attn, pre + ".2", din, true);
+        L.tail_kind = last ? 1 : 0;
+        u->add_conv(L.tail, pre + ".3", dout, din, last ? 3 : 4, true);
+    }
+    const int mid = u->dims.back();
+    u->add_res(u->mid1, "mid_block1", mid, mid);
+    u->add_attn(u->mid_attn, "mid_attn", mid, false);
+    u->add_res(u->mid2, "mid_block2", mid, mid);
+    for (int i = 0; i < u->nres; ++i) {
+        const int din = u->dims[u->nres - 1 - i], dout = u->dims[u->nres - i];
+        const bool last = i == u->nres - 1;
+        const std::string pre = "ups." + std::to_string(i);
+        LevelPlan& L = u->ups[i];
+        u->add_res(L.b1, pre + ".0", dout + din, dout);
+        u->add_res(L.b2, pre + ".1", dout + din, dout);
+        u->add_attn(L.attn, pre + ".2", dout, true);
+        L.tail_kind = last ? 1 : 2;
+        u->add_conv(L.tail, last ? pre + ".3" : pre + ".3.1", din, dout, 3, true);
+    }
+    u->add_res(u->fin, "final_res_block", c.dim * 2, c.dim);
+    if (u->init_dim != c.dim) return fail(TEDM_EINVAL, "init_dim != dim is not supported (final_res_block expects 2*dim inputs)");
+    u->add_param("final_conv.weight", (long long)u->out_dim * c.dim);
+    u->add_param("final_conv.bias", u->out_dim);
+    for (int d : u->dims)
+        if (d % 32 || d % c.groups) return fail(TEDM_EINVAL, "every level width must be a multiple of 32 and of groups");
+
+    for (ConvW* w : u->convs) {
+        w->bytes = conv_packed_bytes(w->cout, w->cin, w->k * w->k);
+        if (hipMalloc(&w->wpk, w->bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc(%zu) for %s failed", w->bytes, w->key.c_str());
+    }
+    if (hipMalloc((void**)&u->film_w, (size_t)u->film_J * u->tdim * 4) != hipSuccess ||
+        hipMalloc((void**)&u->film_b, (size_t)u->film_J * 4) != hipSuccess)
+        return fail(TEDM_ENOMEM, "hipMalloc for FiLM weights failed");
+    return TEDM_OK;
+}
+
+struct Fwd {
+    tedm_unet* u; Arena* A; hipStream_t st; bool dry; int B; int prec; bool film; float* filmbuf; bool tracing;
+
+    int conv(const ConvW& w, const float* x1, int C1, const float* x2, int C2, int H, int W, int Ho, int Wo, float* out,
+             int stride, int ups, int pro, const float* pa, const float* pb, const float* add, const float* add_a,
+             const float* add_b, float* stats, int stats_mode) {
+        if (dry) return TEDM_OK;
+        ConvArgs a{};
+        a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = w.cout;
+        a.wpk = w.wpk; a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
+        a.pro_a = pa; a.pro_b = pb; a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b;
+        a.stats = stats; a.stats_mode = stats_mode; a.prec = prec;
+        const int rc = conv_launch(a, w.k, stride, ups, pro, st);
+        if (rc != TEDM_OK) return fail(rc, "conv launch failed for %s (k=%d cin=%d cout=%d)", w.key.c_str(), w.k, C1 + C2, w.cout);
+        return TEDM_OK;
+    }
+    void record(const std::string& name, const float* p, int H, int W, int C) {
+        if (!tracing || dry) return;
+        u->trace.push_back({name, (size_t)((const char*)p - A->base), {B, H, W, C}});
+    }
+
+    // ResnetBlock (models/unet_model.py:138-175).  out_buf may be caller-provided.
+    int resblock(const ResPlan& r, const float* x1, int C1, const float* x2, int C2, int H, int W, float** out,
+                 float** lnstats) {
+        const long long hw = (long long)H * W;
+        const int C = r.cout;
+        const int E = conv_stats_entries(3, 1, C, H, W);
+        float* slab = A->alloc((size_t)B * E * C * 2);
+        float* y1 = A->alloc((size_t)B * hw * C);
+        float* ga = A->alloc((size_t)B * C);
+        float* gb = A->alloc((size_t)B * C);
+        CHECK(conv(r.c1, x1, C1, x2, C2, H, W, H, W, y1, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
+        if (!dry) CHECK(op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block1.norm.weight"),
+                                       u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr,
+                                       u->film_J, ga, gb, st));
+        float* y2 = A->alloc((size_t)B * hw * C);
+        CHECK(conv(r.c2, y1, C, nullptr, 0, H, W, H, W, y2, 1, 0, PRO_GN, ga, gb, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
+        A->release(y1);
+        if (!dry) CHECK(op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
+                                       u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, st));
+        float* o = A->alloc((size_t)B * hw * C);
+        float* ln = lnstats ? A->alloc((size_t)B * hw * 2) : nullptr;
+        if (r.has_res) {
+            CHECK(conv(r.res, x1, C1, x2, C2, H, W, H, W, o, 1, 0, PRO_NONE, nullptr, nullptr, y2, ga, gb, nullptr, STATS_NONE));
+            if (ln && !dry) CHECK(op_ln_stats(o, ln, (long long)B * hw, C, st));
+        } else {
+            if (!dry) CHECK(op_resblock_out(y2, ga, gb, x1, o, ln, B, hw, C, st));
+        }
+        A->release(y2); A->release(slab); A->release(ga); A->release(gb);
+        *out = o;
+        if (lnstats) *lnstats = ln;
+        record(r.pre, o, H, W, C);
+        return TEDM_OK;
+    }
+
+    // Residual(PreNorm(LinearAttention)) (models/unet_model.py:178-210, :29-36, :64-73)
+    int linattn(const AttnPlan& a, const float* x, const float* ln, int H, int W, float* out_buf, float** out) {
+        const long long hw = (long long)H * W, P = (long long)B * hw;
+        const int C = a.C, C3 = 3 * u->hidden, heads = u->cfg.heads;
+        float* qkv = A->alloc((size_t)P * C3);
+        const int E = conv_stats_entries(1, 1, C3, H, W);
+        float* slab = A->alloc((size_t)B * E * C3);
+        CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_MAX));
+        float* kmax = A->alloc((size_t)B * C3);
+        if (!dry) CHECK(op_colmax_finalize(slab, E, C3, B, kmax, st));
+        A->release(slab);
+        float* part = A->alloc(la_ctx_partial_floats(B, heads, hw));
+        float* ctx = A->alloc((size_t)B * heads * 1024);
+        if (!dry) CHECK(op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
+        A->release(part); A->release(kmax);
+        float* o = A->alloc((size_t)P * u->hidden);
+        if (!dry) CHECK(op_linattn_out(qkv, ctx, B, hw, heads, o, st));
+        A->release(qkv); A->release(ctx);
+        float* z = A->alloc((size_t)P * C);
+        CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, z, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
+        A->release(o);
+        float* res = out_buf ? out_buf : A->alloc((size_t)P * C);
+        if (!dry) CHECK(op_ln_res(z, u->P(a.pre + ".fn.fn.to_out.1.g"), x, res, P, C, st));
+        A->release(z);
+        *out = res;
+        record(a.pre, res, H, W, C);
+        return TEDM_OK;
+    }
+
+    // Residual(PreNorm(Attention)) (models/unet_model.py:213-241)
+    int fullattn(const AttnPlan& a, const float* x, const float* ln, int H, int W, float** out) {
+        const long long hw = (long long)H * W, P = (long long)B * hw;
+        const int C = a.C, C3 = 3 * u->hidden, heads = u->cfg.heads;
+        float* qkv = A->alloc((size_t)P * C3);
+        const int E = conv_stats_entries(1, 1, C3, H, W);
+        float* slab = A->alloc((size_t)B * E * C3 * 2);
+        CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
+        float* inv = A->alloc((size_t)B * C3);
+        if (!dry) CHECK(op_colnorm_finalize(slab, E, C3, B, inv, st));
+        A->release(slab);
+        float* o = A->alloc((size_t)P * u->hidden);
+        if (!dry) CHECK(op_full_attention(qkv, inv, B, (int)hw, heads, 16.0f, o, st));
+        A->release(qkv); A->release(inv);
+        float* res = A->alloc((size_t)P * C);
+        CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, res, 1, 0, PRO_NONE, nullptr, nullptr, x, nullptr, nullptr, nullptr, STATS_NONE));
+        A->release(o);
+        *out = res;
+        record(a.pre, res, H, W, C);
+        return TEDM_OK;
+    }
+
+    int run(const float* x, const float* t, int H, int W, float* eps_out, float* const* feat_out, int flags) {
+        const int nres = u->nres, dim = u->cfg.dim;
+        const bool taps_only = flags & TEDM_FWD_TAPS_ONLY;
+        film = t != nullptr;
+        filmbuf = nullptr;
+        float* r = A->alloc((size_t)B * H * W * u->init_dim);
+        if (!dry) CHECK(op_stem_conv(x, u->P("init_conv.weight"), u->P("init_conv.bias"), r, B, u->cfg.channels, H, W, u->init_dim, st));
+        record("init_conv", r, H, W, u->init_dim);
+        if (film) {
+            float* stb = A->alloc((size_t)B * u->tdim);
+            filmbuf = A->alloc((size_t)B * u->film_J);
+            if (!dry) {
+                CHECK(op_time_embed(t, u->P("time_mlp.0.freqs"), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
+                                    u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, st));
+                CHECK(op_film(stb, u->film_w, u->film_b, B, u->tdim, u->film_J, filmbuf, st));
+            }
+            A->release(stb);
+        }
+        std::vector<float*> hs;
+        float* cur = r;
+        int h = H, w = W;
+        for (int i = 0; i < nres; ++i) {
+            const LevelPlan& L = u->downs[i];
+            const int C = u->dims[i];
+            float *h1, *x2, *ln, *att;
+            CHECK(resblock(L.b1, cur, C, nullptr, 0, h, w, &h1, nullptr));
+            if (cur != r) A->release(cur);
+            hs.push_back(h1);
+            CHECK(resblock(L.b2, h1, C, nullptr, 0, h, w, &x2, &ln));
+            CHECK(linattn(L.attn, x2, ln, h, w, nullptr, &att));
+            A->release(x2); A->release(ln);
+            hs.push_back(att);
+            const int Cn = u->dims[i + 1];
+            if (L.tail_kind == 0) {
+                float* d = A->alloc((size_t)B * (h / 2) * (w / 2) * Cn);
+                CHECK(conv(L.tail, att, C, nullptr, 0, h, w, h / 2, w / 2, d, 2, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
+                h /= 2; w /= 2;
+                cur = d;
+            } else {
+                float* d = A->alloc((size_t)B * h * w * Cn);
+                CHECK(conv(L.tail, att, C, nullptr, 0, h, w, h, w, d, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
+                cur = d;
+            }
+            record("downs." + std::to_string(i) + ".3", cur, h, w, Cn);
+        }
+        {
+            const int C = u->dims.back();
+            float *m1, *ln, *ma, *m2;
+            CHECK(resblock(u->mid1, cur, C, nullptr, 0, h, w, &m1, &ln));
+            A->release(cur);
+            CHECK(fullattn(u->mid_attn, m1, ln, h, w, &ma));
+            A->release(m1); A->release(ln);
+            CHECK(resblock(u->mid2, ma, C, nullptr, 0, h, w, &m2, nullptr));
+            A->release(ma);
+            cur = m2;
+        }
+        for (int i = 0; i < nres; ++i) {
+            const LevelPlan& L = u->ups[i];
+            const int din = u->dims[nres - 1 - i], dout = u->dims[nres - i];
+            float *y1, *y2, *ln, *att;
+            float* s = hs.back(); hs.pop_back();
+            CHECK(resblock(L.b1, cur, dout, s, din, h, w, &y1, nullptr));
+            A->release(cur); A->release(s);
+            s = hs.back(); hs.pop_back();
+            CHECK(resblock(L.b2, y1, dout, s, din, h, w, &y2, &ln));
+            A->release(y1); A->release(s);
+            float* fo = (feat_out && feat_out[i]) ? feat_out[i] : nullptr;
+            CHECK(linattn(L.attn, y2, ln, h, w, fo, &att));
+            A->release(y2); A->release(ln);
+            const bool last = i == nres - 1;
+            if (last && taps_only) { A->release(att); cur = nullptr; break; }
+            if (L.tail_kind == 2) {
+                float* d = A->alloc((size_t)B * (2 * h) * (2 * w) * din);
+                CHECK(conv(L.tail, att, dout, nullptr, 0, h, w, 2 * h, 2 * w, d, 1, 1, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
+                h *= 2; w *= 2;
+                cur = d;
+            } else {
+                float* d = A->alloc((size_t)B * h * w * din);
+                CHECK(conv(L.tail, att, dout, nullptr, 0, h, w, h, w, d, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
+                cur = d;
+            }
+            A->release(att);
+            record("ups." + std::to_string(i) + ".3", cur, h, w, din);
+        }
+        if (!taps_only) {
+            float* f;
+            CHECK(resblock(u->fin, cur, dim, r, u->init_dim, h, w, &f, nullptr));
+            A->release(cur);
+            if (!dry) CHECK(op_final_conv(f, u->P("final_conv.weight"), u->P("final_conv.bias"), eps_out, B, (long long)h * w, dim, u->out_dim, st));
+            A->release(f);
+        }
+        A->release(r);
+        if (filmbuf) A->release(filmbuf);
+        return TEDM_OK;
+    }
+};
+
+int check_shape(const tedm_unet* u, int B, int H, int W) {
+    const int f = 1 << (u->nres - 1);
+    if (B < 1 || H < f || W < f || H % f || W % f) return fail(TEDM_EINVAL, "H and W must be positive multiples of %d (got %dx%d, B=%d)", f, H, W, B);
+    if ((long long)B * H * W >= (1ll << 31)) return fail(TEDM_EINVAL, "B*H*W too large");
+    return TEDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tedm_last_error(void) { return g_err; }
+const char* tedm_version(void) { return "tedm_hip 0.1 (gfx950)"; }
+
+int tedm_unet_create(const tedm_unet_cfg* cfg, tedm_unet** out) {
+    g_err[0] = 0;
+    if (!cfg || !out) return fail(TEDM_EINVAL, "null argument");
+    std::unique_ptr<tedm_unet> u(new (std::nothrow) tedm_unet());
+    if (!u) return fail(TEDM_ENOMEM, "out of host memory");
+    u->cfg = *cfg;
+    const int rc = build_plan(u.get());
+    if (rc != TEDM_OK) return rc;
+    *out = u.release();
+    return TEDM_OK;
+}
+
+void tedm_unet_destroy(tedm_unet* h) { delete h; }
+
+int tedm_unet_num_params(const tedm_unet* h) { return h ? (int)h->params.size() : 0; }
+const char* tedm_unet_param_key(const tedm_unet* h, int i) {
+    return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].key.c_str() : nullptr;
+}
+long long tedm_unet_param_numel(const tedm_unet* h, int i) {
+    return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].numel : -1;
+}
+
+int tedm_unet_set_param(tedm_unet* h, const char* key, const void* dev_ptr, long long numel) {
+    g_err[0] = 0;
+    if (!h || !key || !dev_ptr) return fail(TEDM_EINVAL, "null argument");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(TEDM_ENOKEY, "unknown parameter key '%s'", key);
+    Param& p = h->params[it->second];
+    if (p.numel != numel) return fail(TEDM_EINVAL, "parameter '%s': expected %lld elements, got %lld", key, p.numel, numel);
+    if (p.ptr != dev_ptr) h->packed = false;
+    p.ptr = (const float*)dev_ptr;
+    return TEDM_OK;
+}
+
+int tedm_unet_pack(tedm_unet* h, void* stream) {
+    g_err[0] = 0;
+    if (!h) return fail(TEDM_EINVAL, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    for (const Param& p : h->params)
+        if (!p.ptr) return fail(TEDM_ESTATE, "parameter '%s' is not bound", p.key.c_str());
+    for (ConvW* c : h->convs)
+        CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, st));
+    for (ResPlan* r : h->resblocks) {
+        CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.weight"), h->film_w + (size_t)r->film_off * h->tdim, (long long)2 * r->cout * h->tdim, st));
+        CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.bias"), h->film_b + r->film_off, 2 * r->cout, st));
+    }
+    h->packed = true;
+    return TEDM_OK;
+}
+
+size_t tedm_unet_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags) {
+    g_err[0] = 0;
+    if (!h || check_shape(h, B, H, W) != TEDM_OK) return 0;
+    Arena A;
+    A.dry = true; A.keep = flags & TEDM_FWD_TRACE;
+    Fwd f{const_cast<tedm_unet*>(h), &A, nullptr, true, B, 0, true, nullptr, false};
+    static const float dummy_t = 0.f;
+    float* taps[TEDM_MAX_LEVELS] = {nullptr};
+    if (f.run(nullptr, &dummy_t, H, W, nullptr, taps, flags) != TEDM_OK) return 0;
+    return A.peak + 256;
+}
+
+int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H, int W, float* eps_out,
+                      float* const* feat_out, void* workspace, size_t workspace_bytes, void* stream, int flags) {
+    g_err[0] = 0;
+    if (!h || !x || !workspace) return fail(TEDM_EINVAL, "null argument");
+    if (!(flags & TEDM_FWD_TAPS_ONLY) && !eps_out) return fail(TEDM_EINVAL, "eps_out is required unless TEDM_FWD_TAPS_ONLY");
+    if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
+    CHECK(check_shape(h, B, H, W));
+    const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
+    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    Arena A;
+    const size_t mis = (size_t)((uintptr_t)workspace & 255);
+    A.base = (char*)workspace + (mis ? 256 - mis : 0);
+    A.cap = workspace_bytes - (mis ? 256 - mis : 0);
+    A.dry = false; A.keep = flags & TEDM_FWD_TRACE;
+    h->trace.clear();
+    Fwd f{h, &A, (hipStream_t)stream, false, B, prec, t != nullptr, nullptr, (bool)(flags & TEDM_FWD_TRACE)};
+    // The arena hands out addresses before checking capacity, so size-check with a dry run first.
+    const size_t need = tedm_unet_workspace_bytes(h, B, H, W, flags);
+    if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
+    if (workspace_bytes < need) return fail(TEDM_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const int rc = f.run(x, t, H, W, eps_out, feat_out, flags);
+    if (rc != TEDM_OK) return rc;
+    if (A.oom) return fail(TEDM_ENOMEM, "workspace overflow");
+    if (hipGetLastError() != hipSuccess) return fail(TEDM_EHIP, "HIP launch error");
+    return TEDM_OK;
+}
+
+int tedm_unet_trace_count(const tedm_unet* h) { return h ? (int)h->trace.size() : 0; }
+const char* tedm_unet_trace_name(const tedm_unet* h, int i) {
+    return (h && i >= 0 && i < (int)h->trace.size()) ? h->trace[i].name.c_str() : nullptr;
+}
+int tedm_unet_trace_info(const tedm_unet* h, int i, size_t* byte_offset, int* shape4) {
+    if (!h || i < 0 || i >= (int)h->trace.size()) return TEDM_EINVAL;
+    if (byte_offset) *byte_offset = h->trace[i].off;
+    if (shape4) memcpy(shape4, h->trace[i].shape, sizeof(int) * 4);
+    return TEDM_OK;
+}
+
+int tedm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1macp,
+                  int T, float* x_t, int B, long long chw, int normalize, void* stream) {
+    g_err[0] = 0;
+    if (!x0 || !noise || !t || !sqrt_acp || !sqrt_1macp || !x_t || B < 1 || chw < 1 || T < 1) return fail(TEDM_EINVAL, "bad argument");
+    return op_q_sample(x0, noise, (const long long*)t, sqrt_acp, sqrt_1macp, T, x_t, B, chw, normalize, (hipStream_t)stream);
+}
+
+int tedm_tap_to_features(const float* tap, int B, int h, int w, int C, float* feats, int C_total, int c_off, int S, void* stream) {
+    g_err[0] = 0;
+    if (!tap || !feats || B < 1 || h < 1 || w < 1 || C < 1 || c_off < 0 || c_off + C > C_total || S < 1) return fail(TEDM_EINVAL, "bad argument");
+    return op_tap_to_features(tap, B, h, w, C, feats, C_total, c_off, S, (hipStream_t)stream);
+}
+
+int tedm_set_tuning(const char* key, int value) {
+    g_err[0] = 0;
+    if (!key) return fail(TEDM_EINVAL, "null key");
+    const int rc = conv_set_tuning(key, value);
+    return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
+}
+
+// ---- op-level entry point (tests): one nn.Conv2d through the implicit-GEMM kernel -------------
+int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
+                   const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
+                   const float* ln_g, const float* ln_stats, const float* add, const float* add_a, const float* add_b,
+                   float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = C1 + C2;
+    if (!x1 || !weight_oihw || !out || Cin % 16) return fail(TEDM_EINVAL, "bad argument");
+    int Ho, Wo;
+    if (k == 4 && stride == 2) { Ho = H / 2; Wo = W / 2; }
+    else if ((k == 3 || k == 1) && stride == 1) { Ho = upsample ? 2 * H : H; Wo = upsample ? 2 * W : W; }
+    else return fail(TEDM_EINVAL, "unsupported conv geometry k=%d stride=%d", k, stride);
+    void* wpk = nullptr;
+    const size_t bytes = conv_packed_bytes(Cout, Cin, k * k);
+    if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, st);
+    if (rc == TEDM_OK) {
+        ConvArgs a{};
+        a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+        a.wpk = wpk; a.bias = bias;
+        int pro = PRO_NONE;
+        if (gn_a) { pro = PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        else if (ln_g) { pro = PRO_LN; a.pro_a = ln_g; a.pro_b = ln_stats; }
+        a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b; a.stats = stats; a.stats_mode = stats ? stats_mode : STATS_NONE;
+        a.prec = prec;
+        if (stats_entries) *stats_entries = conv_stats_entries(k, stride, Cout, Ho, Wo);
+        rc = conv_launch(a, k, stride, upsample, pro, st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(wpk);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d failed (%d)", rc);
+}
+
+int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo) { return conv_stats_entries(k, stride, Cout, Ho, Wo); }
+
+}  // extern "C"

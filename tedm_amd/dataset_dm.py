@@ -1,0 +1,81 @@
+"""`DatasetDM` -- drop-in for models/datasetDM_model.py:30-88 (LEDM / LEDMe / TEDM feature extractor).
+
+The reference hooks `diffusion_model.model.ups[i][2]`, runs the UNet once per timestep, copies every
+hooked tensor to the CPU, resizes there and moves the 960*T-channel result back to the device
+(:16-27,67-88).  Here the T noised copies are stacked into ONE native forward of B*T images (the UNet
+has no cross-sample op), the tail of the decoder that feeds no tap is skipped (TEDM_FWD_TAPS_ONLY),
+and the nearest-resize + channel concat is a HIP kernel writing the (B, 960*T, S, S) tensor directly
+on the device.  Values and channel order ([t0: tap0..tap3, t1: ...]) are the reference's.
+"""
+from __future__ import annotations
+
+import os
+from argparse import Namespace
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .diffusion import DiffusionModel
+
+
+class DatasetDM(nn.Module):
+    def __init__(self, args: Namespace) -> None:
+        super().__init__()
+        path = getattr(args, 'saved_diffusion_model', None)
+        if not path or not os.path.isfile(path):                              # datasetDM_model.py:34-37
+            self.diffusion_model = DiffusionModel(args)
+            if getattr(args, 'verbose', False):
+                print(f'No model found at {path}. Please load model!')
+        else:                                                                  # :38-43 (Namespace pickled inside)
+            ckpt = torch.load(path, map_location=torch.device(getattr(args, 'device', 'cpu')), weights_only=False)
+            self.diffusion_model = DiffusionModel(ckpt['config'])
+            self.diffusion_model.load_state_dict(ckpt['model_state_dict'])
+        self.diffusion_model.eval()
+        self._features = {}
+        self.steps = list(args.t_steps_to_save)
+        self.max_images_per_forward = int(getattr(args, 'max_images_per_forward', 64))
+        feat_ch = sum(s[3] for s in self.diffusion_model.model._tap_shapes(1, 8, 8))   # 960 for the default UNet
+        self.feature_channels = feat_ch
+        self.classifier = nn.Sequential(                                       # datasetDM_model.py:57-64
+            nn.Conv2d(feat_ch * len(self.steps), 128, 1), nn.ReLU(), nn.BatchNorm2d(128),
+            nn.Conv2d(128, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
+
+    @torch.no_grad()
+    def extract_features(self, x_0: Tensor, noise: Optional[Tensor] = None) -> Tensor:
+        """datasetDM_model.py:67-83.  Returns (B, feature_channels*T, S, S) fp32 on x_0's device."""
+        if noise is not None:
+            assert x_0.shape == noise.shape
+        dm, unet = self.diffusion_model, self.diffusion_model.model
+        B, _, H, W = x_0.shape
+        assert H == W, 'extract_features resizes to [x.shape[-1]]*2 (datasetDM_model.py:81): square inputs only'
+        S, T, dev = W, len(self.steps), x_0.device
+        feats = torch.empty(B, self.feature_channels * T, S, S, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        per_call = max(1, self.max_images_per_forward // B) if B <= self.max_images_per_forward else 1
+        for s0 in range(0, T, per_call):
+            steps = self.steps[s0:s0 + per_call]
+            xs, ts = [], []
+            for st in steps:
+                t = torch.full((B,), int(st), dtype=torch.long, device=dev)
+                x_t, _ = dm.forward_diffusion_model(x_0=x_0, t=t, noise=noise)   # un-normalised x_0 (:76)
+                xs.append(x_t)
+                ts.append(t)
+            _, taps = unet.native_forward(torch.cat(xs, 0), torch.cat(ts, 0), taps_only=True)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                for j in range(len(steps)):
+                    c_off = (s0 + j) * self.feature_channels
+                    for tap in taps:                                         # tap: (B*Tc, C, h, w) view of NHWC
+                        nhwc = tap.permute(0, 2, 3, 1)[j * B:(j + 1) * B]
+                        assert nhwc.is_contiguous()
+                        _, h, w, Cc = nhwc.shape
+                        _lib.check(L.tedm_tap_to_features(nhwc.data_ptr(), B, h, w, Cc, feats.data_ptr(),
+                                                          feats.shape[1], c_off, S, stream), 'tedm_tap_to_features')
+                        c_off += Cc
+        return feats
+
+    def forward(self, x: Tensor) -> Tensor:
+        """datasetDM_model.py:85-88."""
+        return self.classifier(self.extract_features(x).to(x.device))

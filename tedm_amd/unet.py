@@ -1,0 +1,341 @@
+"""`Unet` -- drop-in for the reference denoiser (models/unet_model.py:246-368) whose forward runs
+as hand-written HIP kernels on MI355X through libtedm_hip.so.
+
+What is kept from the reference surface:
+  * constructor signature and defaults (unet_model.py:247-259), `**kwargs` swallowed;
+  * `forward(x, timestep=None, cond=None)` -- `cond` accepted and ignored (:333-368);
+  * the module tree / attribute names, so `state_dict()` has the reference's 276 keys and a
+    reference checkpoint loads unchanged; parameters are ordinary nn.Parameters (torch default
+    initialisation, as in the reference);
+  * `model.ups[i]` unpacks as (block1, block2, attn, upsample) and forward hooks registered on
+    `attn` receive the post-residual decoder-attention output (models/datasetDM_model.py:50-53).
+
+The sub-modules are parameter containers: the arithmetic of the whole forward is one call into the
+native library (no per-layer PyTorch ops, no CPU fallback).  Calling a sub-module on its own raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+def _native_only(name: str):
+    raise NotImplementedError(
+        f'{name}: sub-modules of tedm_amd.Unet are parameter containers; the arithmetic runs inside '
+        'Unet.forward (libtedm_hip.so). Stand-alone sub-module calls are not supported.')
+
+
+class _Container(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        _native_only(type(self).__name__)
+
+
+class SinusoidalPosEmb(_Container):
+    """models/unet_model.py:76-93.  Holds the frequency table, computed on the CPU exactly as the
+    reference does (exp(arange(half) * -(ln 1e4 / (half-1))) in fp32) and bound to the kernel."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        half = dim // 2
+        freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        self.register_buffer('freqs', freqs.float(), persistent=False)
+
+
+class LayerNorm(_Container):
+    """models/unet_model.py:52-61 (gain only)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+
+class Block(_Container):
+    """models/unet_model.py:119-135."""
+
+    def __init__(self, dim: int, dim_out: int, groups: int = 8):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim_out, 3, padding=1)
+        self.norm = nn.GroupNorm(groups, dim_out)
+        self.act = nn.SiLU()
+
+
+class ResnetBlock(_Container):
+    """models/unet_model.py:138-175."""
+
+    def __init__(self, dim: int, dim_out: int, *, time_emb_dim: Optional[int] = None, groups: int = 8):
+        super().__init__()
+        self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, dim_out * 2)) \
+            if time_emb_dim is not None else None
+        self.block1 = Block(dim, dim_out, groups=groups)
+        self.block2 = Block(dim_out, dim_out, groups=groups)
+        self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+
+
+class LinearAttention(_Container):
+    """models/unet_model.py:178-210."""
+
+    def __init__(self, dim: int, heads: int = 4, dim_head: int = 32):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Sequential(nn.Conv2d(hidden, dim, 1), LayerNorm(dim))
+
+
+class Attention(_Container):
+    """models/unet_model.py:213-241."""
+
+    def __init__(self, dim: int, heads: int = 4, dim_head: int = 32, scale: int = 16):
+        super().__init__()
+        self.scale = scale
+        self.heads = heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(hidden, dim, 1)
+
+
+class PreNorm(_Container):
+    """models/unet_model.py:64-73."""
+
+    def __init__(self, dim: int, fn: nn.Module):
+        super().__init__()
+        self.fn = fn
+        self.norm = LayerNorm(dim)
+
+
+class Residual(nn.Module):
+    """models/unet_model.py:29-36.  In this build the module is the *tap point*: Unet.forward hands
+    it the tensor the native forward produced for this block and it returns it unchanged, so that
+    forward hooks (DatasetDM, models/datasetDM_model.py:50-53) observe the reference's value."""
+
+    def __init__(self, fn: nn.Module):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x, *args, _native_out: Optional[Tensor] = None, **kwargs):
+        if _native_out is None:
+            _native_only('Residual')
+        return _native_out
+
+
+def Upsample(dim: int, dim_out: Optional[int] = None) -> nn.Sequential:
+    """models/unet_model.py:39-44."""
+    return nn.Sequential(nn.Upsample(scale_factor=2, mode='nearest'), nn.Conv2d(dim, dim_out or dim, 3, padding=1))
+
+
+def Downsample(dim: int, dim_out: Optional[int] = None) -> nn.Conv2d:
+    """models/unet_model.py:47-49."""
+    return nn.Conv2d(dim, dim_out or dim, 4, 2, 1)
+
+
+class Unet(nn.Module):
+    def __init__(self, dim: int = 64, init_dim: Optional[int] = None, out_dim: Optional[int] = None,
+                 dim_mults: Sequence[int] = (1, 2, 4, 8), channels: int = 1, resnet_block_groups: int = 8,
+                 learned_variance: bool = False, learned_sinusoidal_cond: bool = False,
+                 learned_sinusoidal_dim: int = 16, **kwargs):
+        super().__init__()
+        if learned_sinusoidal_cond:
+            raise NotImplementedError('learned_sinusoidal_cond=True is not on the TEDM hot path '
+                                      '(config.py never sets it) and has no HIP kernel')
+        self.channels = channels
+        init_dim = init_dim if init_dim is not None else dim
+        dim_mults = tuple(int(m) for m in dim_mults)
+        self.init_conv = nn.Conv2d(channels, init_dim, 7, padding=3)
+        dims = [init_dim, *[dim * m for m in dim_mults]]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        time_dim = dim * 4
+        self.learned_sinusoidal_cond = False
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(dim), nn.Linear(dim, time_dim), nn.GELU(),
+                                      nn.Linear(time_dim, time_dim))
+
+        def rb(a, b):
+            return ResnetBlock(a, b, time_emb_dim=time_dim, groups=resnet_block_groups)
+
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        n = len(in_out)
+        for ind, (d_in, d_out) in enumerate(in_out):
+            last = ind >= n - 1
+            self.downs.append(nn.ModuleList([
+                rb(d_in, d_in), rb(d_in, d_in), Residual(PreNorm(d_in, LinearAttention(d_in))),
+                Downsample(d_in, d_out) if not last else nn.Conv2d(d_in, d_out, 3, padding=1)]))
+        mid = dims[-1]
+        self.mid_block1 = rb(mid, mid)
+        self.mid_attn = Residual(PreNorm(mid, Attention(mid)))
+        self.mid_block2 = rb(mid, mid)
+        for ind, (d_in, d_out) in enumerate(reversed(in_out)):
+            last = ind == n - 1
+            self.ups.append(nn.ModuleList([
+                rb(d_out + d_in, d_out), rb(d_out + d_in, d_out), Residual(PreNorm(d_out, LinearAttention(d_out))),
+                Upsample(d_out, d_in) if not last else nn.Conv2d(d_out, d_in, 3, padding=1)]))
+        self.out_dim = out_dim if out_dim is not None else channels * (1 if not learned_variance else 2)
+        self.final_res_block = rb(dim * 2, dim)
+        self.final_conv = nn.Conv2d(dim, self.out_dim, 1)
+
+        # ---- native side -----------------------------------------------------------------
+        self._cfg = dict(dim=dim, init_dim=init_dim, out_dim=self.out_dim, dim_mults=dim_mults, channels=channels,
+                         groups=resnet_block_groups, heads=4, dim_head=32)
+        self._handle = None
+        self._handle_device = None
+        self._fingerprint = None
+        self._bound: List[Tensor] = []          # keeps converted parameter copies alive
+        self._workspace: Optional[Tensor] = None
+        self.precision = os.environ.get('TEDM_PREC', 'bf16x3')   # 'bf16x3' (parity mode) | 'bf16'
+        self.last_trace: Dict[str, Tensor] = {}
+
+    # -- native handle ---------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, '_handle', None):
+                _lib.lib().tedm_unet_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _ensure_handle(self, device: torch.device):
+        L = _lib.lib()
+        if self._handle is not None and self._handle_device == device:
+            return
+        if self._handle is not None:
+            L.tedm_unet_destroy(self._handle)
+            self._handle = None
+        c = self._cfg
+        cfg = _lib.UnetCfg()
+        cfg.dim, cfg.init_dim, cfg.out_dim = c['dim'], c['init_dim'], c['out_dim']
+        cfg.n_mults = len(c['dim_mults'])
+        for i, m in enumerate(c['dim_mults']):
+            cfg.dim_mults[i] = m
+        cfg.channels, cfg.groups, cfg.heads, cfg.dim_head = c['channels'], c['groups'], c['heads'], c['dim_head']
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.tedm_unet_create(C.byref(cfg), C.byref(h)), 'tedm_unet_create')
+        self._handle, self._handle_device, self._fingerprint = h, device, None
+
+    def _native_tensors(self) -> Dict[str, Tensor]:
+        sd = {k: v for k, v in self.named_parameters()}
+        sd['time_mlp.0.freqs'] = self.time_mlp[0].freqs
+        return sd
+
+    def _sync_params(self, device: torch.device, stream_ptr: int):
+        """(Re)bind parameter pointers and repack when anything changed (load_state_dict,
+        optimizer step, .to())."""
+        L = _lib.lib()
+        tensors = self._native_tensors()
+        fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values())
+        if fp == self._fingerprint:
+            return
+        self._bound = []
+        n = L.tedm_unet_num_params(self._handle)
+        want = {L.tedm_unet_param_key(self._handle, i).decode() for i in range(n)}
+        if want != set(tensors):
+            raise _lib.TedmError(f'parameter set mismatch between facade and native plan: '
+                                 f'{sorted(want ^ set(tensors))[:8]}')
+        for k, t in tensors.items():
+            if t.device != device:
+                raise RuntimeError(f'parameter {k} is on {t.device}, input on {device}')
+            tt = t.detach()
+            if tt.dtype != torch.float32 or not tt.is_contiguous():
+                tt = tt.float().contiguous()
+            self._bound.append(tt)
+            _lib.check(L.tedm_unet_set_param(self._handle, k.encode(), tt.data_ptr(), tt.numel()), f'set_param({k})')
+        _lib.check(L.tedm_unet_pack(self._handle, stream_ptr), 'tedm_unet_pack')
+        self._fingerprint = fp
+
+    def _flags(self, taps_only: bool, trace: bool) -> int:
+        if self.precision not in _lib.PREC_BY_NAME:
+            raise ValueError(f'unknown precision {self.precision!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
+        f = _lib.PREC_BY_NAME[self.precision] << _lib.FWD_PREC_SHIFT
+        if taps_only:
+            f |= _lib.FWD_TAPS_ONLY
+        if trace:
+            f |= _lib.FWD_TRACE
+        return f
+
+    def _tap_shapes(self, B: int, H: int, W: int):
+        c = self._cfg
+        dims = [c['init_dim'], *[c['dim'] * m for m in c['dim_mults']]]
+        n = len(c['dim_mults'])
+        out = []
+        for i in range(n):
+            lvl = n - 1 - i                       # ups[i] runs at encoder level n-1-i
+            f = 2 ** min(lvl, n - 1)
+            out.append((B, H // f, W // f, dims[n - i]))
+        return out
+
+    # -- the hot path ----------------------------------------------------------------------
+    def native_forward(self, x: Tensor, timestep: Optional[Tensor], *, want_taps: bool = False,
+                       taps_only: bool = False, trace: bool = False):
+        """Run the HIP forward. Returns (eps or None, [4 taps as NCHW-shaped channels_last views] or None)."""
+        if not x.is_cuda:
+            raise RuntimeError('tedm_amd.Unet runs on a ROCm GPU only: there is no CPU fallback '
+                               '(use oracle/ for a CPU restatement in tests)')
+        if x.dim() != 4 or x.shape[1] != self.channels:
+            raise ValueError(f'expected input (B,{self.channels},H,W), got {tuple(x.shape)}')
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError('tedm_amd.Unet: backward kernels are not implemented yet; '
+                                      'call under torch.no_grad()')
+        L = _lib.lib()
+        dev = x.device
+        B, _, H, W = x.shape
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._ensure_handle(dev)
+            self._sync_params(dev, stream)
+            xin = x.detach().float().contiguous()
+            tin = None
+            if timestep is not None:
+                tin = timestep.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if tin.numel() != B:
+                    raise ValueError(f'timestep must have {B} elements, got {tin.numel()}')
+            flags = self._flags(taps_only, trace)
+            need = L.tedm_unet_workspace_bytes(self._handle, B, H, W, flags)
+            if need == 0:
+                _lib.check(-1, f'workspace sizing for input {tuple(x.shape)}')
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            eps = None if taps_only else torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=dev)
+            taps = None
+            feat_ptrs = None
+            if want_taps or taps_only:
+                taps = [torch.empty(s, dtype=torch.float32, device=dev) for s in self._tap_shapes(B, H, W)]
+                feat_ptrs = (C.c_void_p * len(taps))(*[t.data_ptr() for t in taps])
+            _lib.check(L.tedm_unet_forward(
+                self._handle, xin.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
+                eps.data_ptr() if eps is not None else None, feat_ptrs, self._workspace.data_ptr(),
+                self._workspace.numel(), stream, flags), 'tedm_unet_forward')
+            if trace:
+                self.last_trace = self._read_trace()
+            if taps is not None:
+                taps = [t.permute(0, 3, 1, 2) for t in taps]     # NCHW-shaped views of the NHWC buffers
+        return eps, taps
+
+    def _read_trace(self) -> Dict[str, Tensor]:
+        L = _lib.lib()
+        out = {}
+        for i in range(L.tedm_unet_trace_count(self._handle)):
+            name = L.tedm_unet_trace_name(self._handle, i).decode()
+            off = C.c_size_t()
+            shp = (C.c_int * 4)()
+            _lib.check(L.tedm_unet_trace_info(self._handle, i, C.byref(off), shp), 'trace_info')
+            b, h, w, c = list(shp)
+            n = b * h * w * c
+            flat = self._workspace[off.value: off.value + 4 * n].view(torch.float32)
+            out[name] = flat.view(b, h, w, c).permute(0, 3, 1, 2).clone()
+        return out
+
+    def forward(self, x: Tensor, timestep: Optional[Tensor] = None, cond: Optional[Tensor] = None) -> Tensor:
+        hooked = any(len(lvl[2]._forward_hooks) or len(lvl[2]._forward_pre_hooks) for lvl in self.ups)
+        eps, taps = self.native_forward(x, timestep, want_taps=hooked)
+        if hooked:
+            for lvl, tap in zip(self.ups, taps):
+                lvl[2](tap, _native_out=tap)          # fires the registered forward hooks
+        return eps
