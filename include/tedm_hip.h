@@ -58,8 +58,9 @@ typedef struct tedm_unet_cfg {
     int dim_head;                  /* attention head width (32) */
 } tedm_unet_cfg;
 
-/* Unet.__init__ (models/unet_model.py:247-331): builds the layer plan and allocates the
- * handle-owned packed-weight buffers on the current HIP device. */
+/* Unet.__init__ (models/unet_model.py:247-331): builds the layer plan (host only; the
+ * handle-owned packed-weight buffers are allocated on the current HIP device by the first
+ * tedm_unet_pack()). */
 int  tedm_unet_create(const tedm_unet_cfg* cfg, tedm_unet** out);
 void tedm_unet_destroy(tedm_unet* h);
 

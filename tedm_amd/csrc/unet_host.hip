@@ -224,13 +224,7 @@ int build_plan(tedm_unet* u) {
     for (int d : u->dims)
         if (d % 32 || d % c.groups) return fail(TEDM_EINVAL, "every level width must be a multiple of 32 and of groups");
 
-    for (ConvW* w : u->convs) {
-        w->bytes = conv_packed_bytes(w->cout, w->cin, w->k * w->k);
-        if (hipMalloc(&w->wpk, w->bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc(%zu) for %s failed", w->bytes, w->key.c_str());
-    }
-    if (hipMalloc((void**)&u->film_w, (size_t)u->film_J * u->tdim * 4) != hipSuccess ||
-        hipMalloc((void**)&u->film_b, (size_t)u->film_J * 4) != hipSuccess)
-        return fail(TEDM_ENOMEM, "hipMalloc for FiLM weights failed");
+    for (ConvW* w : u->convs) w->bytes = conv_packed_bytes(w->cout, w->cin, w->k * w->k);
     return TEDM_OK;
 }
 
@@ -491,6 +485,14 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (const Param& p : h->params)
         if (!p.ptr) return fail(TEDM_ESTATE, "parameter '%s' is not bound", p.key.c_str());
+    // handle-owned packed buffers are allocated on first pack (create() itself touches no device)
+    for (ConvW* w : h->convs)
+        if (!w->wpk && hipMalloc(&w->wpk, w->bytes) != hipSuccess)
+            return fail(TEDM_ENOMEM, "hipMalloc(%zu) for %s failed", w->bytes, w->key.c_str());
+    if (!h->film_w && hipMalloc((void**)&h->film_w, (size_t)h->film_J * h->tdim * 4) != hipSuccess)
+        return fail(TEDM_ENOMEM, "hipMalloc for FiLM weights failed");
+    if (!h->film_b && hipMalloc((void**)&h->film_b, (size_t)h->film_J * 4) != hipSuccess)
+        return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
     for (ConvW* c : h->convs)
         CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, st));
     for (ResPlan* r : h->resblocks) {

@@ -1,0 +1,121 @@
+"""CPU: the C-ABI library loads and exports every symbol the headers declare; the facade keeps the
+reference's state-dict contract; host-side plan / workspace logic; no compute is launched."""
+import ctypes as C
+import json
+import re
+from argparse import Namespace
+
+import pytest
+import torch
+
+from oracle import unet_ref as O
+
+
+def header_functions(root):
+    names = []
+    for h in sorted((root / 'include').glob('*.h')):
+        text = re.sub(r'/\*.*?\*/', '', h.read_text(), flags=re.S)
+        names += re.findall(r'\b(tedm_[a-z0-9_]+)\s*\(', text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from tests.conftest import ROOT
+    lib = C.CDLL(str(built_lib))
+    declared = header_functions(ROOT)
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/ but not exported'
+    from tedm_amd import _lib
+    assert set(_lib.EXPORTED_SYMBOLS) == set(declared)
+
+
+def test_state_dict_contract(golden_dir):
+    from tedm_amd import Unet
+    want = json.loads((golden_dir / 'unet_d64_state_dict_keys.json').read_text())
+    sd = Unet(64, dim_mults=(1, 2, 4, 8), channels=1).state_dict()
+    assert list(sd.keys()) == list(want.keys())
+    assert all(list(sd[k].shape) == want[k] for k in want)
+    assert sum(v.numel() for v in sd.values()) == 36245377
+
+
+def test_native_plan_matches_facade(built_lib):
+    from tedm_amd import Unet, _lib
+    L = _lib.lib()
+    for dim in (64, 32):
+        m = Unet(dim)
+        cfg = _lib.UnetCfg()
+        cfg.dim, cfg.n_mults, cfg.channels, cfg.groups, cfg.heads, cfg.dim_head = dim, 4, 1, 8, 4, 32
+        for i, v in enumerate((1, 2, 4, 8)):
+            cfg.dim_mults[i] = v
+        h = C.c_void_p()
+        _lib.check(L.tedm_unet_create(C.byref(cfg), C.byref(h)))
+        n = L.tedm_unet_num_params(h)
+        native = {L.tedm_unet_param_key(h, i).decode(): L.tedm_unet_param_numel(h, i) for i in range(n)}
+        facade = {k: v.numel() for k, v in m._native_tensors().items()}
+        assert native == facade
+        assert L.tedm_unet_workspace_bytes(h, 32, 256, 256, 0) > (1 << 30)
+        assert L.tedm_unet_workspace_bytes(h, 2, 60, 64, 0) == 0          # H not divisible by 8
+        assert L.tedm_unet_workspace_bytes(h, 2, 64, 64, _lib.FWD_TAPS_ONLY) <= L.tedm_unet_workspace_bytes(h, 2, 64, 64, 0)
+        L.tedm_unet_destroy(h)
+
+
+def test_bad_config_is_rejected(built_lib):
+    from tedm_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.UnetCfg()
+    cfg.dim, cfg.n_mults, cfg.channels, cfg.groups, cfg.heads, cfg.dim_head = 24, 4, 1, 8, 4, 32
+    h = C.c_void_p()
+    assert L.tedm_unet_create(C.byref(cfg), C.byref(h)) != 0
+    assert b'multiple of 32' in L.tedm_last_error()
+
+
+def test_no_cpu_fallback():
+    from tedm_amd import DiffusionModel, Unet
+    m = Unet(32)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        with torch.no_grad():
+            m(torch.zeros(1, 1, 16, 16), torch.zeros(1))
+    with pytest.raises(NotImplementedError):
+        m.downs[0][0](torch.zeros(1, 32, 16, 16))
+    cfg = Namespace(normalize=True, dim=32)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        DiffusionModel(cfg).forward_diffusion_model(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))
+
+
+def test_diffusion_buffers_match_oracle():
+    from tedm_amd import DiffusionModel
+    for sched in ('cosine', 'linear'):
+        dm = DiffusionModel(Namespace(normalize=True, dim=32, beta_schedule=sched, p2_loss_weight_gamma=1.0))
+        bufs = O.diffusion_buffers(1000, sched, p2_gamma=1.0)
+        for k, v in bufs.items():
+            assert torch.equal(getattr(dm, k), v), k
+    with pytest.raises(ValueError):
+        DiffusionModel(Namespace(normalize=True, dim=32, beta_schedule='nope'))
+
+
+def test_synth_weights_deterministic():
+    from tedm_amd import Unet, load_synth_weights, synth_state_dict
+    a, b = Unet(32), Unet(32)
+    load_synth_weights(a, seed=3)
+    load_synth_weights(b, seed=3)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+    s = synth_state_dict({k: tuple(v.shape) for k, v in a.state_dict().items()}, 3)
+    assert all(torch.equal(s[k], a.state_dict()[k]) for k in s)
+    load_synth_weights(b, seed=4)
+    assert not torch.equal(a.init_conv.weight, b.init_conv.weight)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """Reference checkpoint format (trainers/train_CXR14.py:96-102) loads into the facade."""
+    from tedm_amd import DiffusionModel, load_synth_weights
+    cfg = Namespace(normalize=True, dim=32, dim_mults=(1, 2, 4, 8), channels=1)
+    dm = DiffusionModel(cfg)
+    load_synth_weights(dm.model, seed=1)
+    path = tmp_path / 'best_model.pt'
+    torch.save({'model_state_dict': dm.state_dict(), 'optimizer_state_dict': {}, 'config': cfg, 'step': 5}, path)
+    ck = torch.load(path, weights_only=False)
+    dm2 = DiffusionModel(ck['config'])
+    dm2.load_state_dict(ck['model_state_dict'])
+    assert all(torch.equal(a, b) for a, b in zip(dm.state_dict().values(), dm2.state_dict().values()))

@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/unet_ref.py) against the golden vectors produced by the imported reference
+(oracle/make_golden.py, run in the build container).  This is what pins the oracle."""
+import json
+
+import numpy as np
+import torch
+
+from oracle import unet_ref as O
+from tedm_amd.weights import synth_state_dict
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).norm() / b.norm())
+
+
+def weights(golden_dir, dim, seed):
+    if dim == 64:
+        shapes = {k: tuple(v) for k, v in json.loads((golden_dir / 'unet_d64_state_dict_keys.json').read_text()).items()}
+    else:
+        from tedm_amd.unet import Unet
+        shapes = {k: tuple(v.shape) for k, v in Unet(dim).state_dict().items()}
+    return synth_state_dict(shapes, seed)
+
+
+def test_q_sample_and_eps_64(golden_dir):
+    g = np.load(golden_dir / 'eps_d64_s64.npz')
+    w = weights(golden_dir, 64, 0)
+    bufs = O.diffusion_buffers()
+    x_t = O.q_sample(bufs, torch.from_numpy(g['x0']) * 2 - 1, torch.from_numpy(g['t']), torch.from_numpy(g['noise']))
+    assert torch.equal(x_t, torch.from_numpy(g['x_t']))
+    eps, taps = O.unet_forward(w, x_t, torch.from_numpy(g['t']), return_taps=True)
+    assert rel(eps, g['eps']) < 1e-6
+    for i, tp in enumerate(taps):
+        assert rel(tp[:, ::4, ::2, ::2], g[f'tap{i}_sub']) < 1e-6
+        assert rel(tp.mean(dim=(2, 3)), g[f'tap{i}_mean']) < 1e-5
+
+
+def test_eps_no_timestep(golden_dir):
+    g = np.load(golden_dir / 'eps_d64_s64_notime.npz')
+    assert rel(O.unet_forward(weights(golden_dir, 64, 0), torch.from_numpy(g['x_t']), None), g['eps']) < 1e-6
+
+
+def test_eps_256(golden_dir):
+    g = np.load(golden_dir / 'eps_d64_s256.npz')
+    eps = O.unet_forward(weights(golden_dir, 64, 0), torch.from_numpy(g['x_t']), torch.from_numpy(g['t']))
+    assert rel(eps, g['eps']) < 1e-6
+
+
+def test_module_trace_mini(golden_dir):
+    g = np.load(golden_dir / 'trace_d32_s16.npz')
+    w = weights(golden_dir, 32, 3)
+    eps, trace = O.unet_forward(w, torch.from_numpy(g['x_t']), torch.from_numpy(g['t']), dim=32, return_trace=True)
+    assert rel(eps, g['eps']) < 1e-6
+    names = [k[2:] for k in g.files if k.startswith('m:')]
+    assert len(names) == 37
+    for nm in names:
+        assert rel(trace[nm], g['m:' + nm]) < 1e-6, nm
+
+
+def test_extract_features(golden_dir):
+    g = np.load(golden_dir / 'extract_d32_s16.npz')
+    f = O.extract_features(weights(golden_dir, 32, 3), O.diffusion_buffers(), torch.from_numpy(g['x0']),
+                           list(g['steps']), torch.from_numpy(g['noise']), dim=32)
+    assert f.shape == (2, 480 * 3, 16, 16)
+    assert rel(f[:, ::7], g['feats_sub']) < 1e-6
+    assert rel(f.mean(dim=(2, 3)), g['feats_mean']) < 1e-5
+
+
+def test_classifier_and_loss(golden_dir):
+    g = np.load(golden_dir / 'classifier_d64_s16.npz')
+    w = weights(golden_dir, 64, 0)
+    bufs = O.diffusion_buffers()
+    f = O.extract_features(w, bufs, torch.from_numpy(g['x0']), list(g['steps']), torch.from_numpy(g['noise']))
+    assert f.shape == (2, 2880, 16, 16)
+    assert rel(f.mean(dim=(2, 3)), g['feats_mean']) < 1e-5
+    shapes = {'0.weight': (128, 2880, 1, 1), '0.bias': (128,), '2.weight': (128,), '2.bias': (128,),
+              '2.running_mean': (128,), '2.running_var': (128,), '3.weight': (32, 128, 1, 1), '3.bias': (32,),
+              '5.weight': (32,), '5.bias': (32,), '5.running_mean': (32,), '5.running_var': (32,),
+              '6.weight': (1, 32, 1, 1), '6.bias': (1,)}
+    assert rel(O.pixel_classifier(synth_state_dict(shapes, 5), f), g['logits']) < 1e-5
+    gl = np.load(golden_dir / 'loss_d64_s64.npz')
+    loss = O.train_loss(w, bufs, torch.from_numpy(gl['x0']), torch.from_numpy(gl['t']), torch.from_numpy(gl['noise']))
+    assert abs(float(loss) - float(gl['loss'])) < 1e-5
