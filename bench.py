@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- denoise-step throughput of the MI355X-native TEDM UNet (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one synthetic batch that is already resident in HBM:
+q-sample (x0, t, noise -> x_t) followed by the UNet noise-prediction forward, reference defaults
+(Unet(dim=64, dim_mults=(1,2,4,8), channels=1), 36.2 M parameters), batch 32 x 1 x 256 x 256 per GPU
+(BASELINE configs[1]).  Weights are the build's deterministic synthetic generator (no trained TEDM
+checkpoint ships with the reference), data is synthetic.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, the batch of images is sharded across ranks (weak scaling, 32 images per
+GPU, no data-path collective -- the forward has no cross-sample op); RCCL is used only for the
+barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E spec, same guide (6.29 TB/s measured copy)
+A_FLOPS_PER_IMG_256 = 236.27e9   # SURVEY.md 8d (scales with S^2 up to the 0.5 GF attention term)
+A_BYTES_PER_IMG_256 = 939.3e6    # SURVEY.md 8d barrier model, bf16 activations (this build stores fp32: 2x)
+T_ROOF_PER_IMG_256 = 159.24e-6   # SURVEY.md App. B stage-wise roofline at nominal peaks, bf16 storage
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
+    ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
+    args = ap.parse_args()
+
+    import torch
+    from tedm_amd import DiffusionModel, _lib, load_synth_weights
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the HIP path has no CPU fallback)'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    L = _lib.lib()
+    if args.tile_wide is not None:
+        _lib.check(L.tedm_set_tuning(b'conv_tile_wide', args.tile_wide))
+
+    B, S, K, W = args.batch, args.size, args.steps, args.warmup
+    cfg = Namespace(normalize=True, dim=64, dim_mults=(1, 2, 4, 8), channels=1, timesteps=1000,
+                    beta_schedule='cosine', objective='pred_noise')
+    dm = DiffusionModel(cfg)
+    load_synth_weights(dm.model, seed=0)
+    dm = dm.to(dev).eval()
+    dm.model.precision = args.prec
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    x0 = torch.rand(B, 1, S, S, generator=g).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    noise = torch.randn(B, 1, S, S, generator=g).to(dev)
+
+    def step():
+        x_t = dm._q_sample(x0, t, noise, normalize=True)
+        return dm.model(x_t, t)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(W):
+            eps = step()
+        # ---- timed region: exactly K steps, barrier + synchronize on both sides ----------------
+        L.tedm_profile_reset()
+        L.tedm_profile_enable(1)                 # event pairs around the convolution launches only
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            eps = step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        L.tedm_profile_enable(0)
+        conv_prof = _lib.profile_entries()
+        if dist is not None:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+
+        breakdown = None
+        if args.breakdown and rank == 0:
+            L.tedm_profile_reset()
+            L.tedm_profile_enable(2)
+            for _ in range(max(1, K // 4)):
+                step()
+            torch.cuda.synchronize(dev)
+            L.tedm_profile_enable(0)
+            breakdown = _lib.profile_entries()
+
+    imgs = world * B * K
+    value = imgs / elapsed
+    ms_per_step = 1e3 * elapsed / K
+
+    out = {
+        'metric': 'denoise-step images/sec @256x256 bs32 per GPU (UNet eps forward)', 'value': round(value, 2),
+        'unit': 'img/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x3' if args.prec == 'bf16x3' else 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': f'TEDM Unet(dim=64,dim_mults=(1,2,4,8),channels=1) q-sample + eps forward, '
+                               f'{B}x1x{S}x{S} per GPU (BASELINE configs[1])',
+                   'images_per_gpu': B, 'image_size': S, 'params': 36245377,
+                   'precision': ('bf16 hi/lo split MFMA (3 products), fp32 accumulate, fp32 activations in HBM'
+                                 if args.prec == 'bf16x3' else 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM'),
+                   'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream -------
+        conv_prof.sort(key=lambda e: -e[2])
+        if conv_prof:
+            name, launches, ms, flops, byts = conv_prof[0]
+            achieved = flops / (ms * 1e-3) / 1e12
+            conv_ms = sum(e[2] for e in conv_prof)
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'launches': launches, 'avg_us': round(1e3 * ms / launches, 2),
+                'alg_gflop_per_launch': round(flops / launches / 1e9, 3),
+                'alg_mb_per_launch': round(byts / launches / 1e6, 3),
+                'kernel_share_of_step': round(ms / (1e3 * elapsed), 4),
+                'all_conv_share_of_step': round(conv_ms / (1e3 * elapsed), 4),
+                'all_conv_tflops': round(sum(e[3] for e in conv_prof) / (conv_ms * 1e-3) / 1e12, 2),
+            }
+        per_img = elapsed / (B * K)
+        scale = (S / 256.0) ** 2
+        out['whole_step'] = {
+            't_roof_frac': round(T_ROOF_PER_IMG_256 * scale / per_img, 4),
+            'mfma_frac': round(A_FLOPS_PER_IMG_256 * scale / per_img / (PEAK_BF16_TFLOPS * 1e12), 4),
+            'hbm_frac_bf16_model': round(A_BYTES_PER_IMG_256 * scale / per_img / (PEAK_HBM_GBS * 1e9), 4),
+            'us_per_image': round(per_img * 1e6, 2),
+        }
+        if breakdown:
+            breakdown.sort(key=lambda e: -e[2])
+            tot = sum(e[2] for e in breakdown)
+            print('--- per-kernel HIP-event breakdown (separate pass) ---', file=sys.stderr)
+            for name, n, ms, fl, by in breakdown:
+                print(f'{ms / tot * 100:6.2f}%  {ms / n * 1e3:9.1f} us x {n:5d}  {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF/s '
+                      f'{by / (ms * 1e-3) / 1e9 if ms else 0:8.0f} GB/s  {name}', file=sys.stderr)
+
+        # ---- CPU baseline (rank 0, N=1): the oracle restatement on the host cores, bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import unet_ref as O
+            ncores = os.cpu_count() or 1
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            torch.set_num_threads(ncores)
+            w = {k: v.detach().cpu() for k, v in dm.model.state_dict().items()}
+            bufs = O.diffusion_buffers()
+            nb = min(4, B)
+            xc, tc, nc = x0[:nb].cpu(), t[:nb].cpu(), noise[:nb].cpu()
+            with torch.no_grad():
+                O.diffusion_forward(w, bufs, xc[:1], tc[:1], nc[:1])          # warm-up
+                c0 = time.perf_counter()
+                reps = 2
+                for _ in range(reps):
+                    ref = O.diffusion_forward(w, bufs, xc, tc, nc)
+                cpu_s = time.perf_counter() - c0
+            err = float((eps[:nb].cpu() - ref).norm() / ref.norm())
+            out['cpu_baseline'] = {'value': round(reps * nb / cpu_s, 3), 'unit': 'img/s', 'cores': torch.get_num_threads(),
+                                   'kind': 'port',
+                                   'sample': f'{reps} x {nb}x1x{S}x{S} fp32 q-sample+UNet forward (oracle/unet_ref.py, torch CPU ops), 1 warm-up'}
+            out['eps_rel_l2_vs_cpu'] = float(f'{err:.3e}')
+            out['eps_gate'] = 1e-3
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -32,6 +32,17 @@ int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
  * convolutions with >= 128 output channels (conv_igemm.hip). */
 int tedm_set_tuning(const char* key, int value);
 
+/* HIP-event profiler (bench.py's live roofline): brackets kernel launches on the launch stream with
+ * event pairs.  level 0 off, 1 convolutions only, 2 every kernel of the forward.  After the timed
+ * region call tedm_profile_collect() (synchronises on the recorded events), then read the entries:
+ * kernel label (== rocprof symbol for the convolutions), launches, total ms, total algorithmic
+ * flops and bytes. */
+int tedm_profile_enable(int level);
+int tedm_profile_reset(void);
+int tedm_profile_collect(void);
+int tedm_profile_count(void);
+int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, double* ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,12 @@ _SIGNATURES = {
                                   C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                   C.POINTER(C.c_int), C.c_int, _P]),
     'tedm_op_conv2d_stats_entries': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_profile_enable': (C.c_int, [C.c_int]),
+    'tedm_profile_reset': (C.c_int, []),
+    'tedm_profile_collect': (C.c_int, []),
+    'tedm_profile_count': (C.c_int, []),
+    'tedm_profile_entry': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -77,3 +83,16 @@ def check(rc: int, what: str = '') -> None:
     if rc != 0:
         msg = lib().tedm_last_error().decode(errors='replace')
         raise TedmError(f'{what or "libtedm_hip"} failed (code {rc}): {msg}')
+
+
+def profile_entries():
+    """[(label, launches, ms, flops, bytes)] accumulated since the last tedm_profile_reset()."""
+    L = lib()
+    check(L.tedm_profile_collect(), 'tedm_profile_collect')
+    out = []
+    for i in range(L.tedm_profile_count()):
+        name = C.create_string_buffer(192)
+        n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+        check(L.tedm_profile_entry(i, name, 192, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        out.append((name.value.decode(), n.value, ms.value, fl.value, by.value))
+    return out

@@ -70,6 +70,7 @@ struct ConvArgs {
 int conv_launch(const ConvArgs& a, int KH, int stride, int ups, int pro, hipStream_t st);
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo);   // E of the stats slab
 size_t conv_packed_bytes(int Cout, int Cin, int taps);
+void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap);
 
 // ---- pack.hip -------------------------------------------------------------------------
 int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, hipStream_t st);

@@ -25,6 +25,7 @@
 //     128-B segments, and per-output-channel sum/sumsq (GroupNorm, l2norm) or max (k-softmax)
 //     partials written to a deterministic slab (no atomics).
 #include "common.h"
+#include <stdio.h>
 #include <string.h>
 #include "../../include/tedm_hip.h"
 
@@ -326,6 +327,15 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 2) { g_tile_wide = v; return TEDM_OK; }
     return TEDM_EINVAL;
+}
+
+// Label == the rocprof kernel symbol (template argument list of conv_igemm_kernel).
+void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
+    const int id = select_tile_id(a.Cout);
+    const TileSel t = tile_geom(id, stride);
+    const int pad = KH == 1 ? 0 : 1, ks = KH == 1 ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
+    snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
+             ks, nbuf, pro, a.prec == TEDM_PREC_BF16 ? TEDM_PREC_BF16 : TEDM_PREC_BF16X3);
 }
 
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {

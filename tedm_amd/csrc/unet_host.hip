@@ -95,6 +95,51 @@ struct Arena {
 
 struct Trace { std::string name; size_t off; int shape[4]; };
 
+// HIP-event profiler: brackets kernel launches ON THE LAUNCH STREAM with event pairs and accumulates
+// per-kernel launches / time / algorithmic flops / algorithmic bytes.  level 1: convolutions only,
+// level 2: every kernel of the forward.  Durations are resolved in tedm_profile_collect().
+struct ProfEntry { std::string name; long long launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct Profiler {
+    int level = 0;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Rec { int entry; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<ProfEntry> entries;
+    std::map<std::string, int> idx;
+    int cur = -1; hipEvent_t cur_a = nullptr;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+    void begin(const std::string& name, double flops, double bytes, hipStream_t st) {
+        auto it = idx.find(name);
+        int i;
+        if (it == idx.end()) { i = (int)entries.size(); idx[name] = i; entries.push_back({name}); } else i = it->second;
+        entries[i].launches++; entries[i].flops += flops; entries[i].bytes += bytes;
+        cur = i; cur_a = get();
+        if (cur_a) (void)hipEventRecord(cur_a, st);
+    }
+    void end(hipStream_t st) {
+        if (cur < 0) return;
+        hipEvent_t b = get();
+        if (cur_a && b) { (void)hipEventRecord(b, st); pending.push_back({cur, cur_a, b}); }
+        cur = -1;
+    }
+    int collect() {
+        for (const Rec& r : pending) {
+            if (hipEventSynchronize(r.b) != hipSuccess) return TEDM_EHIP;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return TEDM_EHIP;
+            entries[r.entry].ms += ms;
+        }
+        pending.clear(); used = 0;
+        return TEDM_OK;
+    }
+    void reset() { (void)collect(); entries.clear(); idx.clear(); }
+};
+Profiler g_prof;
+
 }  // namespace
 
 struct tedm_unet {
@@ -228,6 +273,16 @@ int build_plan(tedm_unet* u) {
     return TEDM_OK;
 }
 
+#define OP(NAME, FLOPS, BYTES, CALL)                                              \
+    do {                                                                          \
+        if (!dry) {                                                               \
+            if (g_prof.level >= 2) g_prof.begin(NAME, FLOPS, BYTES, st);          \
+            const int _r = (CALL);                                                \
+            if (g_prof.level >= 2) g_prof.end(st);                                \
+            CHECK(_r);                                                            \
+        }                                                                         \
+    } while (0)
+
 struct Fwd {
     tedm_unet* u; Arena* A; hipStream_t st; bool dry; int B; int prec; bool film; float* filmbuf; bool tracing;
 
@@ -240,7 +295,15 @@ struct Fwd {
         a.wpk = w.wpk; a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
         a.pro_a = pa; a.pro_b = pb; a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b;
         a.stats = stats; a.stats_mode = stats_mode; a.prec = prec;
+        if (g_prof.level >= 1) {
+            char label[160];
+            conv_kernel_label(a, w.k, stride, ups, pro, label, sizeof(label));
+            const double cin = C1 + C2;
+            g_prof.begin(label, 2.0 * B * Ho * Wo * w.cout * cin * w.k * w.k,
+                         4.0 * B * ((double)H * W * cin + (double)Ho * Wo * w.cout * (add ? 2 : 1)), st);
+        }
         const int rc = conv_launch(a, w.k, stride, ups, pro, st);
+        if (g_prof.level >= 1) g_prof.end(st);
         if (rc != TEDM_OK) return fail(rc, "conv launch failed for %s (k=%d cin=%d cout=%d)", w.key.c_str(), w.k, C1 + C2, w.cout);
         return TEDM_OK;
     }
@@ -260,21 +323,22 @@ struct Fwd {
         float* ga = A->alloc((size_t)B * C);
         float* gb = A->alloc((size_t)B * C);
         CHECK(conv(r.c1, x1, C1, x2, C2, H, W, H, W, y1, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
-        if (!dry) CHECK(op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block1.norm.weight"),
-                                       u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr,
-                                       u->film_J, ga, gb, st));
+        OP("gn_finalize", 0.0, 8.0 * B * E * C,
+           op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block1.norm.weight"),
+                          u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr, u->film_J, ga, gb, st));
         float* y2 = A->alloc((size_t)B * hw * C);
         CHECK(conv(r.c2, y1, C, nullptr, 0, H, W, H, W, y2, 1, 0, PRO_GN, ga, gb, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
         A->release(y1);
-        if (!dry) CHECK(op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
-                                       u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, st));
+        OP("gn_finalize", 0.0, 8.0 * B * E * C,
+           op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
+                          u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, st));
         float* o = A->alloc((size_t)B * hw * C);
         float* ln = lnstats ? A->alloc((size_t)B * hw * 2) : nullptr;
         if (r.has_res) {
             CHECK(conv(r.res, x1, C1, x2, C2, H, W, H, W, o, 1, 0, PRO_NONE, nullptr, nullptr, y2, ga, gb, nullptr, STATS_NONE));
-            if (ln && !dry) CHECK(op_ln_stats(o, ln, (long long)B * hw, C, st));
+            if (ln) OP("ln_stats", 0.0, 4.0 * B * hw * C, op_ln_stats(o, ln, (long long)B * hw, C, st));
         } else {
-            if (!dry) CHECK(op_resblock_out(y2, ga, gb, x1, o, ln, B, hw, C, st));
+            OP(ln ? "resblock_out+ln_stats" : "resblock_out", 0.0, 12.0 * B * hw * C, op_resblock_out(y2, ga, gb, x1, o, ln, B, hw, C, st));
         }
         A->release(y2); A->release(slab); A->release(ga); A->release(gb);
         *out = o;
@@ -292,20 +356,20 @@ struct Fwd {
         float* slab = A->alloc((size_t)B * E * C3);
         CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_MAX));
         float* kmax = A->alloc((size_t)B * C3);
-        if (!dry) CHECK(op_colmax_finalize(slab, E, C3, B, kmax, st));
+        OP("colmax_finalize", 0.0, 4.0 * B * E * C3, op_colmax_finalize(slab, E, C3, B, kmax, st));
         A->release(slab);
         float* part = A->alloc(la_ctx_partial_floats(B, heads, hw));
         float* ctx = A->alloc((size_t)B * heads * 1024);
-        if (!dry) CHECK(op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
+        OP("linattn_context", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
         A->release(part); A->release(kmax);
         float* o = A->alloc((size_t)P * u->hidden);
-        if (!dry) CHECK(op_linattn_out(qkv, ctx, B, hw, heads, o, st));
+        OP("linattn_out", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_out(qkv, ctx, B, hw, heads, o, st));
         A->release(qkv); A->release(ctx);
         float* z = A->alloc((size_t)P * C);
         CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, z, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
         A->release(o);
         float* res = out_buf ? out_buf : A->alloc((size_t)P * C);
-        if (!dry) CHECK(op_ln_res(z, u->P(a.pre + ".fn.fn.to_out.1.g"), x, res, P, C, st));
+        OP("ln_res", 0.0, 12.0 * P * C, op_ln_res(z, u->P(a.pre + ".fn.fn.to_out.1.g"), x, res, P, C, st));
         A->release(z);
         *out = res;
         record(a.pre, res, H, W, C);
@@ -321,10 +385,10 @@ struct Fwd {
         float* slab = A->alloc((size_t)B * E * C3 * 2);
         CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
         float* inv = A->alloc((size_t)B * C3);
-        if (!dry) CHECK(op_colnorm_finalize(slab, E, C3, B, inv, st));
+        OP("colnorm_finalize", 0.0, 8.0 * B * E * C3, op_colnorm_finalize(slab, E, C3, B, inv, st));
         A->release(slab);
         float* o = A->alloc((size_t)P * u->hidden);
-        if (!dry) CHECK(op_full_attention(qkv, inv, B, (int)hw, heads, 16.0f, o, st));
+        OP("full_attention", 128.0 * B * heads * (double)hw * hw, 4.0 * P * (C3 + u->hidden), op_full_attention(qkv, inv, B, (int)hw, heads, 16.0f, o, st));
         A->release(qkv); A->release(inv);
         float* res = A->alloc((size_t)P * C);
         CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, res, 1, 0, PRO_NONE, nullptr, nullptr, x, nullptr, nullptr, nullptr, STATS_NONE));
@@ -340,16 +404,17 @@ struct Fwd {
         film = t != nullptr;
         filmbuf = nullptr;
         float* r = A->alloc((size_t)B * H * W * u->init_dim);
-        if (!dry) CHECK(op_stem_conv(x, u->P("init_conv.weight"), u->P("init_conv.bias"), r, B, u->cfg.channels, H, W, u->init_dim, st));
+        OP("stem_conv7x7", 98.0 * B * H * W * u->init_dim * u->cfg.channels, 4.0 * B * H * W * (u->cfg.channels + u->init_dim),
+           op_stem_conv(x, u->P("init_conv.weight"), u->P("init_conv.bias"), r, B, u->cfg.channels, H, W, u->init_dim, st));
         record("init_conv", r, H, W, u->init_dim);
         if (film) {
             float* stb = A->alloc((size_t)B * u->tdim);
             filmbuf = A->alloc((size_t)B * u->film_J);
-            if (!dry) {
-                CHECK(op_time_embed(t, u->P("time_mlp.0.freqs"), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
-                                    u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, st));
-                CHECK(op_film(stb, u->film_w, u->film_b, B, u->tdim, u->film_J, filmbuf, st));
-            }
+            OP("time_embed", 2.0 * B * u->tdim * (dim + u->tdim), 4.0 * u->tdim * (dim + u->tdim),
+               op_time_embed(t, u->P("time_mlp.0.freqs"), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
+                             u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, st));
+            OP("film_proj", 2.0 * B * u->tdim * u->film_J, 4.0 * u->tdim * u->film_J,
+               op_film(stb, u->film_w, u->film_b, B, u->tdim, u->film_J, filmbuf, st));
             A->release(stb);
         }
         std::vector<float*> hs;
@@ -422,7 +487,8 @@ struct Fwd {
             float* f;
             CHECK(resblock(u->fin, cur, dim, r, u->init_dim, h, w, &f, nullptr));
             A->release(cur);
-            if (!dry) CHECK(op_final_conv(f, u->P("final_conv.weight"), u->P("final_conv.bias"), eps_out, B, (long long)h * w, dim, u->out_dim, st));
+            OP("final_conv1x1", 2.0 * B * h * w * dim * u->out_dim, 4.0 * B * h * w * (dim + u->out_dim),
+               op_final_conv(f, u->P("final_conv.weight"), u->P("final_conv.bias"), eps_out, B, (long long)h * w, dim, u->out_dim, st));
             A->release(f);
         }
         A->release(r);
@@ -564,6 +630,21 @@ int tedm_tap_to_features(const float* tap, int B, int h, int w, int C, float* fe
     g_err[0] = 0;
     if (!tap || !feats || B < 1 || h < 1 || w < 1 || C < 1 || c_off < 0 || c_off + C > C_total || S < 1) return fail(TEDM_EINVAL, "bad argument");
     return op_tap_to_features(tap, B, h, w, C, feats, C_total, c_off, S, (hipStream_t)stream);
+}
+
+int tedm_profile_enable(int level) { g_prof.level = level < 0 ? 0 : level; return TEDM_OK; }
+int tedm_profile_reset(void) { g_prof.reset(); return TEDM_OK; }
+int tedm_profile_collect(void) { g_err[0] = 0; const int rc = g_prof.collect(); return rc == TEDM_OK ? rc : fail(rc, "event timing failed"); }
+int tedm_profile_count(void) { return (int)g_prof.entries.size(); }
+int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, double* ms, double* flops, double* bytes) {
+    if (i < 0 || i >= (int)g_prof.entries.size()) return TEDM_EINVAL;
+    const ProfEntry& e = g_prof.entries[i];
+    if (name && name_cap > 0) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = e.launches;
+    if (ms) *ms = e.ms;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return TEDM_OK;
 }
 
 int tedm_set_tuning(const char* key, int value) {
