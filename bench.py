@@ -35,6 +35,30 @@ A_BYTES_PER_IMG_256 = 939.3e6    # SURVEY.md 8d barrier model, bf16 activations 
 T_ROOF_PER_IMG_256 = 159.24e-6   # SURVEY.md App. B stage-wise roofline at nominal peaks, bf16 storage
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read_text())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -178,11 +202,7 @@ def main() -> None:
         # ---- CPU baseline (rank 0, N=1): the oracle restatement on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import unet_ref as O
-            ncores = os.cpu_count() or 1
-            try:
-                ncores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            ncores = host_cores()
             torch.set_num_threads(ncores)
             w = {k: v.detach().cpu() for k, v in dm.model.state_dict().items()}
             bufs = O.diffusion_buffers()
