@@ -27,6 +27,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 #include "../../include/tedm_hip.h"
 
 namespace {
@@ -165,63 +166,95 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
 
     const uint4* wq = (const uint4*)a.wpk;
     const int lane_a = (STRIDE == 1 ? (wm * MT * G::HC + r) : (wm * MT * G::HC2 + r)) * G::PSTRIDE + h * 16;
+    const int NC = a.nk16 / KS;
 
-    auto compute = [&](int c, int buf) {
+    // Weight fragments are fetched one tap-column group (all ky of one kx) AHEAD of the MFMAs that
+    // consume them; the group's registers are bq[set].  Sets are indexed statically (kx, or the chunk
+    // parity for 1x1) so they stay in VGPRs.
+    constexpr int NSET = KW > 1 ? KW : 2;
+    uint4 bq[NSET][KH][KS][NPL];
+
+    auto load_b = [&](int c, int kx, uint4 (&b)[KH][KS][NPL]) {
+        if (!active) return;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)   // packed layout always carries both planes (hi, lo)
+                    b[ky][ks][p] = wq[((((size_t)ct * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];
+    };
+
+    // All MFMAs of tap column kx for one staged chunk.  Each halo row is read from LDS once and feeds
+    // every ky whose output row it belongs to.
+    auto compute_kx = [&](int buf, int kx, const uint4 (&b)[KH][KS][NPL]) {
         if (!active) return;
         const char* sb = smem + buf * G::BUFSZ + lane_a;
+        constexpr int NPR = MT + (KH - 1) / STRIDE;           // plane rows touched by one row parity
 #pragma unroll
-        for (int ky = 0; ky < KH; ++ky) {
-            uint4 bq[KW][KS][NPL];
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx)
+            for (int py = 0; py < STRIDE; ++py)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int pr = 0; pr < NPR; ++pr) {
+                    const int poff = STRIDE == 1
+                        ? (pr * G::HC + kx)
+                        : ((py * 2 + (kx & 1)) * G::PLANE2 + pr * G::HC2 + (kx >> 1));
+                    const int off = poff * G::PSTRIDE + ks * 32;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off));
+                    bf16x8 al = ah;
+                    if (NPL == 2) al = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off + G::REGION));
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p)
-                        bq[kx][ks][p] = wq[((((size_t)ct * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];  // packed layout always carries hi,lo
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[kx][ks][0]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int poff = STRIDE == 1
-                            ? ((mt + ky) * G::HC + kx)
-                            : (((ky & 1) * 2 + (kx & 1)) * G::PLANE2 + (mt + (ky >> 1)) * G::HC2 + (kx >> 1));
-                        const int off = poff * G::PSTRIDE + ks * 32;
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off));
+                    for (int ky = py; ky < KH; ky += STRIDE) {
+                        const int mt = pr - ky / STRIDE;
+                        if (mt < 0 || mt >= MT) continue;
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, b[ky][ks][0]);
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
                         if (NPL == 2) {
-                            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off + G::REGION));
-                            const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[kx][ks][NPL - 1]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, b[ky][ks][NPL - 1]);
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
                         }
                     }
                 }
+    };
+
+    // one staged chunk: MFMAs of chunk c from LDS buffer `buf`, prefetching the next weight group
+    auto chunk_body = [&](int c, int buf, auto par) {
+        constexpr int PAR = decltype(par)::value;             // chunk parity (used by the 1x1 sets)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            if (KW > 1) {
+                if (kx + 1 < KW) load_b(c, kx + 1, bq[(kx + 1) % NSET]);
+                else if (c + 1 < NC) load_b(c + 1, 0, bq[0]);
+                compute_kx(buf, kx, bq[kx % NSET]);
+            } else {
+                if (c + 1 < NC) load_b(c + 1, 0, bq[PAR ^ 1]);
+                compute_kx(buf, 0, bq[PAR]);
+            }
         }
     };
 
-    const int NC = a.nk16 / KS;
-    if (NBUF == 2) {
-        issue_loads(0);
-        write_lds(0);
-        __syncthreads();
-        for (int c = 0; c < NC; ++c) {
+    load_b(0, 0, bq[0]);
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
+    auto step = [&](int c, auto par) {
+        if (NBUF == 2) {
             if (c + 1 < NC) issue_loads(c + 1);
-            compute(c, c & 1);
+            chunk_body(c, c & 1, par);
             if (c + 1 < NC) write_lds((c + 1) & 1);
             __syncthreads();
+        } else {
+            if (c + 1 < NC) issue_loads(c + 1);
+            chunk_body(c, 0, par);
+            __syncthreads();                                  // everyone done reading the single buffer
+            if (c + 1 < NC) { write_lds(0); __syncthreads(); }
         }
-    } else {
-        for (int c = 0; c < NC; ++c) {
-            issue_loads(c);
-            __syncthreads();
-            write_lds(0);
-            __syncthreads();
-            compute(c, 0);
-        }
+    };
+    for (int c = 0; c < NC; c += 2) {
+        step(c, std::integral_constant<int, 0>{});
+        if (c + 1 < NC) step(c + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue ---------------------------------------------------------------------

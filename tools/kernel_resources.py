@@ -21,5 +21,5 @@ except Exception:
     dem = names
 for r, d in zip(rows, dem):
     d = re.sub(r'\(anonymous namespace\)::', '', d)
-    d = re.sub(r'^void ', '', d); d = re.sub(r'\(.*$', '', d)
-    print(f"{d:70s} vgpr={r.get('vgpr')} agpr={r.get('agpr')} spill={r.get('spill')} scratch={r.get('scratch')} sgpr={r.get('sgpr')} occ={r.get('occ')} lds={r.get('lds')}")
+    d = re.sub(r'^void ', '', d); d = re.sub(r'\(.*$', '', d); d = d.replace(' ', '')
+    print(f"{d:58s} vgpr={r.get('vgpr')} agpr={r.get('agpr')} spill={r.get('spill')} scratch={r.get('scratch')} sgpr={r.get('sgpr')} occ={r.get('occ')} lds={r.get('lds')}")
