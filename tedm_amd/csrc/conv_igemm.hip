@@ -219,15 +219,17 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
                 }
     };
 
-    // one staged chunk: MFMAs of chunk c from LDS buffer `buf`, prefetching the next weight group
+    // one staged chunk: MFMAs of chunk c from LDS buffer `buf`; weight groups are fetched PD groups
+    // ahead (3x3 / 4x4: two tap columns ~ 2 x 36 MFMAs of cover for the L2 latency; 1x1: one chunk).
+    constexpr int PD = KW > 1 ? 2 : 1;
     auto chunk_body = [&](int c, int buf, auto par) {
         constexpr int PAR = decltype(par)::value;             // chunk parity (used by the 1x1 sets)
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             if (KW > 1) {
-                if (kx + 1 < KW) load_b(c, kx + 1, bq[(kx + 1) % NSET]);
-                else if (c + 1 < NC) load_b(c + 1, 0, bq[0]);
-                compute_kx(buf, kx, bq[kx % NSET]);
+                const int kx2 = (kx + PD) % KW, c2 = c + (kx + PD) / KW;
+                if (c2 < NC) load_b(c2, kx2, bq[kx2]);
+                compute_kx(buf, kx, bq[kx]);
             } else {
                 if (c + 1 < NC) load_b(c + 1, 0, bq[PAR ^ 1]);
                 compute_kx(buf, 0, bq[PAR]);
@@ -235,29 +237,38 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
         }
     };
 
-    load_b(0, 0, bq[0]);
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
-    auto step = [&](int c, auto par) {
-        if (NBUF == 2) {
+    if (NBUF == 2) {
+        load_b(0, 0, bq[0]);
+        if (KW > 1) load_b(0, 1, bq[1]);
+        issue_loads(0);
+        write_lds(0);
+        __syncthreads();
+        auto step = [&](int c, auto par) {
             if (c + 1 < NC) issue_loads(c + 1);
             chunk_body(c, c & 1, par);
             if (c + 1 < NC) write_lds((c + 1) & 1);
             __syncthreads();
-        } else {
-            if (c + 1 < NC) issue_loads(c + 1);
-            chunk_body(c, 0, par);
-            __syncthreads();                                  // everyone done reading the single buffer
-            if (c + 1 < NC) { write_lds(0); __syncthreads(); }
+        };
+        for (int c = 0; c < NC; c += 2) {
+            step(c, std::integral_constant<int, 0>{});
+            if (c + 1 < NC) step(c + 1, std::integral_constant<int, 1>{});
         }
-    };
-    for (int c = 0; c < NC; c += 2) {
-        step(c, std::integral_constant<int, 0>{});
-        if (c + 1 < NC) step(c + 1, std::integral_constant<int, 1>{});
+    } else {
+        // single LDS buffer (1x1, HBM-bound): keep registers low so 3-4 workgroups share a CU and
+        // overlap each other's load / MFMA phases; the chunk's weights travel with its activations.
+        for (int c = 0; c < NC; ++c) {
+            load_b(c, 0, bq[0]);
+            issue_loads(c);
+            __syncthreads();
+            write_lds(0);
+            __syncthreads();
+            compute_kx(0, 0, bq[0]);
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------
+    // acc[mt][i]: pixel column ox0 + (i&3) + 8*(i>>2) + 4*h of output row oy0 + wm*MT + mt, channel
+    // ct*32 + r.  A store instruction therefore writes two 128-B segments (32 channels x 2 pixels).
     if (!active) return;
     const int cout = ct * 32 + r;
     const bool cok = cout < a.Cout;
@@ -265,26 +276,55 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
     float aa = 1.f, ab = 0.f;
     if (a.add_a && cok) { aa = a.add_a[(size_t)n * a.Cout + cout]; ab = a.add_b[(size_t)n * a.Cout + cout]; }
     float s1 = 0.f, s2 = 0.f, smax = -INFINITY;
+    const bool full_cols = ox0 + 32 <= a.Wo;                   // block-uniform
+    const int cstride = a.Cout;
+
+    auto emit = [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;           // 0: no addend, 1: plain addend, 2: silu(aa*add+ab)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int oy = oy0 + wm * MT + mt;
-        if (oy >= a.Ho) continue;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oy = oy0 + wm * MT + mt;
+            if (oy >= a.Ho) continue;                          // wave-uniform
+            const size_t rowbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox0 + 4 * h) * cstride + cout;
+            float* op = a.out + rowbase;
+            const float* ap = MODE ? a.add + rowbase : nullptr;
+            if (full_cols) {
+                if (!cok) continue;
+                float ad[16];
+                if (MODE) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (ox < a.Wo && cok) {
-                const size_t o = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + cout;
-                float v = acc[mt][i] + bias;
-                if (a.add) {
-                    float t = a.add[o];
-                    if (a.add_a) t = silu_f(fmaf(aa, t, ab));
-                    v += t;
+                    for (int i = 0; i < 16; ++i) ad[i] = ap[((i & 3) + 8 * (i >> 2)) * cstride];
                 }
-                a.out[o] = v;
-                s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[mt][i] + bias;
+                    if (MODE == 1) v += ad[i];
+                    if (MODE == 2) v += silu_f(fmaf(aa, ad[i], ab));
+                    op[((i & 3) + 8 * (i >> 2)) * cstride] = v;
+                    s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dx = (i & 3) + 8 * (i >> 2);
+                    if (ox0 + 4 * h + dx < a.Wo && cok) {
+                        float v = acc[mt][i] + bias;
+                        if (MODE) {
+                            float t = ap[dx * cstride];
+                            if (MODE == 2) t = silu_f(fmaf(aa, t, ab));
+                            v += t;
+                        }
+                        op[dx * cstride] = v;
+                        s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                    }
+                }
             }
         }
-    }
+    };
+    if (!a.add) emit(std::integral_constant<int, 0>{});
+    else if (!a.add_a) emit(std::integral_constant<int, 1>{});
+    else emit(std::integral_constant<int, 2>{});
+
     if (a.stats_mode != STATS_NONE) {
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); smax = fmaxf(smax, __shfl_xor(smax, 32));
         if (h == 0 && cok) {
