@@ -66,10 +66,11 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16'])
+    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
     ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
+    ap.add_argument('--tile-narrow', type=int, default=None, help='tuning: conv tile id for Cout<128')
     args = ap.parse_args()
 
     import torch
@@ -96,6 +97,8 @@ def main() -> None:
     L = _lib.lib()
     if args.tile_wide is not None:
         _lib.check(L.tedm_set_tuning(b'conv_tile_wide', args.tile_wide))
+    if args.tile_narrow is not None:
+        _lib.check(L.tedm_set_tuning(b'conv_tile_narrow', args.tile_narrow))
 
     B, S, K, W = args.batch, args.size, args.steps, args.warmup
     cfg = Namespace(normalize=True, dim=64, dim_mults=(1, 2, 4, 8), channels=1, timesteps=1000,
@@ -156,13 +159,14 @@ def main() -> None:
     out = {
         'metric': 'denoise-step images/sec @256x256 bs32 per GPU (UNet eps forward)', 'value': round(value, 2),
         'unit': 'img/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x3' if args.prec == 'bf16x3' else 'bf16',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec,
         'data': 'synthetic',
         'config': {'workload': f'TEDM Unet(dim=64,dim_mults=(1,2,4,8),channels=1) q-sample + eps forward, '
                                f'{B}x1x{S}x{S} per GPU (BASELINE configs[1])',
                    'images_per_gpu': B, 'image_size': S, 'params': 36245377,
-                   'precision': ('bf16 hi/lo split MFMA (3 products), fp32 accumulate, fp32 activations in HBM'
-                                 if args.prec == 'bf16x3' else 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM'),
+                   'precision': {'bf16x3': 'bf16 hi/lo split MFMA (3 products), fp32 accumulate, fp32 activations in HBM',
+                                 'bf16': 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM',
+                                 'fp16x2': 'fp16 activations x fp16 hi/lo weights (2 products), fp32 accumulate, fp32 activations in HBM'}[args.prec],
                    'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
     }
 

@@ -37,6 +37,7 @@ extern "C" {
 /* Arithmetic mode of the MFMA contractions (convs, 1x1 projections). */
 #define TEDM_PREC_BF16X3   0   /* default: bf16 hi/lo split, 3 MFMAs, fp32 accumulate (~2^-17 operand error) */
 #define TEDM_PREC_BF16     1   /* single bf16 MFMA, fp32 accumulate (fast; eps error ~1e-2, fails the 1e-3 gate) */
+#define TEDM_PREC_FP16X2   2   /* fp16 activations x (fp16 hi + fp16 lo) weights, 2 MFMAs, fp32 accumulate (experimental) */
 
 /* forward flags */
 #define TEDM_FWD_TAPS_ONLY   (1 << 0)  /* skip ups[last][3], final_res_block, final_conv (feature extraction; eps_out may be NULL) */
@@ -75,9 +76,15 @@ long long   tedm_unet_param_numel(const tedm_unet* h, int i);
  * optimizer changed the values. */
 int tedm_unet_set_param(tedm_unet* h, const char* key, const void* dev_ptr, long long numel);
 
-/* Repack all bound weights into the kernels' internal layouts (bf16 hi/lo MFMA fragment
- * order, concatenated FiLM projection).  Enqueued on `stream`. */
+/* Repack all bound weights into the kernels' internal layouts (hi/lo MFMA fragment order in the
+ * handle's precision mode -- bf16 planes for TEDM_PREC_BF16X3/BF16, fp16 planes for
+ * TEDM_PREC_FP16X2 --, concatenated FiLM projection).  Enqueued on `stream`. */
 int tedm_unet_pack(tedm_unet* h, void* stream);
+
+/* Select the arithmetic mode of the MFMA contractions (TEDM_PREC_*; default BF16X3).  Changing the
+ * weight encoding (bf16 <-> fp16) invalidates the packed weights: call tedm_unet_pack() again.
+ * The precision bits of tedm_unet_forward's flags must name the same mode. */
+int tedm_unet_set_precision(tedm_unet* h, int prec);
 
 /* Workspace size in bytes for a forward of the given shape / flags. */
 size_t tedm_unet_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags);

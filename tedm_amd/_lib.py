@@ -12,9 +12,9 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / 'libtedm_hip.so'
 
 TEDM_MAX_LEVELS = 8
-PREC_BF16X3, PREC_BF16 = 0, 1
+PREC_BF16X3, PREC_BF16, PREC_FP16X2 = 0, 1, 2
 FWD_TAPS_ONLY, FWD_TRACE, FWD_PREC_SHIFT = 1 << 0, 1 << 1, 8
-PREC_BY_NAME = {'bf16x3': PREC_BF16X3, 'bf16': PREC_BF16}
+PREC_BY_NAME = {'bf16x3': PREC_BF16X3, 'bf16': PREC_BF16, 'fp16x2': PREC_FP16X2}
 
 
 class UnetCfg(C.Structure):
@@ -38,6 +38,7 @@ _SIGNATURES = {
     'tedm_unet_param_numel': (C.c_longlong, [_P, C.c_int]),
     'tedm_unet_set_param': (C.c_int, [_P, C.c_char_p, _P, C.c_longlong]),
     'tedm_unet_pack': (C.c_int, [_P, _P]),
+    'tedm_unet_set_precision': (C.c_int, [_P, C.c_int]),
     'tedm_unet_workspace_bytes': (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     'tedm_unet_forward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P), _P, C.c_size_t, _P, C.c_int]),
     'tedm_unet_trace_count': (C.c_int, [_P]),

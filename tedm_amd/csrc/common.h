@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -23,6 +24,25 @@ TEDM_DEVFN void split8(const float (&v)[8], uint4& hi, uint4& lo) {
     }
     hi = __builtin_bit_cast(uint4, h);
     lo = __builtin_bit_cast(uint4, l);
+}
+
+// fp16 variants: hi = fp16(v) (11 significand bits), lo = fp16(v - hi) (22 bits together)
+TEDM_DEVFN void split8_f16(const float (&v)[8], uint4& hi, uint4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 hj = (_Float16)v[j];
+        h[j] = hj;
+        l[j] = (_Float16)(v[j] - (float)hj);
+    }
+    hi = __builtin_bit_cast(uint4, h);
+    lo = __builtin_bit_cast(uint4, l);
+}
+TEDM_DEVFN uint4 cvt8_f16(const float (&v)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    return __builtin_bit_cast(uint4, h);
 }
 
 TEDM_DEVFN float wave_sum(float v) {
@@ -73,5 +93,5 @@ size_t conv_packed_bytes(int Cout, int Cin, int taps);
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap);
 
 // ---- pack.hip -------------------------------------------------------------------------
-int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, hipStream_t st);
+int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int fp16, hipStream_t st);
 int copy_rows(const float* src, float* dst, long long n, hipStream_t st);

@@ -32,7 +32,7 @@
 
 namespace {
 
-template <int KH, int KW, int STRIDE, int WM, int MT, int KS, int NBUF, int PREC>
+template <int KH, int KW, int STRIDE, int WM, int MT, int KS, int NBUF, int PREC, int NTHR = 256>
 struct Geo {
     static constexpr int TR = WM * MT;                       // output rows per tile
     static constexpr int HR = (TR - 1) * STRIDE + KH;        // halo rows / cols
@@ -42,19 +42,21 @@ struct Geo {
     static constexpr int NPIX = STRIDE == 1 ? HR * HC : 4 * PLANE2;
     static constexpr int PSTRIDE = KS * 32 + 16;             // bytes / pixel / precision plane
     static constexpr int REGION = NPIX * PSTRIDE;
-    static constexpr int NPL = PREC == TEDM_PREC_BF16X3 ? 2 : 1;
+    static constexpr int NPL = PREC == TEDM_PREC_BF16X3 ? 2 : 1;           // LDS planes of the activations
     static constexpr int BUFSZ = REGION * NPL;
     static constexpr int LDS = BUFSZ * NBUF;
     static constexpr int PIECES = HR * HC * 2 * KS;          // (halo pixel, 8-channel piece)
-    static constexpr int NIT = (PIECES + 255) / 256;
+    static constexpr int NIT = (PIECES + NTHR - 1) / NTHR;
 };
 
 template <int KH, int KW, int STRIDE, int PAD, int UPS, int WM, int WN, int MT, int KS, int NBUF,
           int PRO, int PREC>
-__global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_kernel(ConvArgs a) {
-    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC>;
+__global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int NTHR = WM * WN * 64;
+    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC, NTHR>;
     constexpr int T = KH * KW;
-    constexpr int NPL = G::NPL;
+    constexpr int NPL = G::NPL;                                  // activation planes (hi[,lo])
+    constexpr int NPB = PREC == TEDM_PREC_BF16 ? 1 : 2;          // weight planes fetched (hi[,lo])
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
     const int piece = tid % (2 * KS);
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
-        const int i = tid + it * 256;
+        const int i = tid + it * NTHR;
         const int pl = i / (2 * KS);
         gp[it] = -2; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
         if (pl < G::HR * G::HC) {
@@ -151,10 +153,14 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
                 }
                 v[j] = x;
             }
-            uint4 hi, lo;
-            split8(v, hi, lo);
-            *(uint4*)(base + lofs[it]) = hi;
-            if (NPL == 2) *(uint4*)(base + G::REGION + lofs[it]) = lo;
+            if (PREC == TEDM_PREC_FP16X2) {
+                *(uint4*)(base + lofs[it]) = cvt8_f16(v);
+            } else {
+                uint4 hi, lo;
+                split8(v, hi, lo);
+                *(uint4*)(base + lofs[it]) = hi;
+                if (NPL == 2) *(uint4*)(base + G::REGION + lofs[it]) = lo;
+            }
         }
     };
 
@@ -172,22 +178,22 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
     // consume them; the group's registers are bq[set].  Sets are indexed statically (kx, or the chunk
     // parity for 1x1) so they stay in VGPRs.
     constexpr int NSET = KW > 1 ? KW : 2;
-    uint4 bq[NSET][KH][KS][NPL];
+    uint4 bq[NSET][KH][KS][NPB];
 
-    auto load_b = [&](int c, int kx, uint4 (&b)[KH][KS][NPL]) {
+    auto load_b = [&](int c, int kx, uint4 (&b)[KH][KS][NPB]) {
         if (!active) return;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p)   // packed layout always carries both planes (hi, lo)
+                for (int p = 0; p < NPB; ++p)   // packed layout always carries both planes (hi, lo)
                     b[ky][ks][p] = wq[((((size_t)ct * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];
     };
 
     // All MFMAs of tap column kx for one staged chunk.  Each halo row is read from LDS once and feeds
     // every ky whose output row it belongs to.
-    auto compute_kx = [&](int buf, int kx, const uint4 (&b)[KH][KS][NPL]) {
+    auto compute_kx = [&](int buf, int kx, const uint4 (&b)[KH][KS][NPB]) {
         if (!active) return;
         const char* sb = smem + buf * G::BUFSZ + lane_a;
         constexpr int NPR = MT + (KH - 1) / STRIDE;           // plane rows touched by one row parity
@@ -201,19 +207,27 @@ __global__ __launch_bounds__(256, (MT * STRIDE >= 8 ? 1 : 2)) void conv_igemm_ke
                         ? (pr * G::HC + kx)
                         : ((py * 2 + (kx & 1)) * G::PLANE2 + pr * G::HC2 + (kx >> 1));
                     const int off = poff * G::PSTRIDE + ks * 32;
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off));
-                    bf16x8 al = ah;
-                    if (NPL == 2) al = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + off + G::REGION));
+                    const uint4 ahq = *(const uint4*)(sb + off);
+                    uint4 alq = ahq;
+                    if (NPL == 2) alq = *(const uint4*)(sb + off + G::REGION);
 #pragma unroll
                     for (int ky = py; ky < KH; ky += STRIDE) {
                         const int mt = pr - ky / STRIDE;
                         if (mt < 0 || mt >= MT) continue;
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, b[ky][ks][0]);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
-                        if (NPL == 2) {
-                            const bf16x8 bl = __builtin_bit_cast(bf16x8, b[ky][ks][NPL - 1]);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+                        if (PREC == TEDM_PREC_FP16X2) {
+                            const f16x8 af = __builtin_bit_cast(f16x8, ahq);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, b[ky][ks][0]), acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, b[ky][ks][NPB - 1]), acc[mt], 0, 0, 0);
+                        } else {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, ahq);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, b[ky][ks][0]);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
+                            if (NPL == 2) {
+                                const bf16x8 al = __builtin_bit_cast(bf16x8, alq);
+                                const bf16x8 bl = __builtin_bit_cast(bf16x8, b[ky][ks][NPB - 1]);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -347,18 +361,27 @@ struct TileSel { int wm, wn, mt; };
 //   id 1 "narrow" : 2x2 waves, 4 M-tiles -> 256 px x  64 cout
 //   id 2 "wide4"  : 1x4 waves, 4 M-tiles -> 128 px x 128 cout
 // stride-2 convs use half the rows (the halo doubles).
+//   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
 int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
+int g_tile_narrow = 1;    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
 
-inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : 1; }
+inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : g_tile_narrow; }
 inline TileSel tile_geom(int id, int stride) {
-    TileSel t = id == 0 ? TileSel{1, 4, 8} : id == 1 ? TileSel{2, 2, 4} : TileSel{1, 4, 4};
-    if (stride == 2) t.mt = t.mt > 2 ? t.mt / 2 : t.mt;
+    TileSel t;
+    switch (id) {
+        case 0: t = TileSel{1, 4, 8}; break;
+        case 1: t = TileSel{2, 2, 4}; break;
+        case 2: t = TileSel{1, 4, 4}; break;
+        case 3: t = TileSel{2, 4, 4}; break;
+        default: t = TileSel{2, 4, 4}; break;
+    }
+    if (stride == 2) t.mt = t.mt > 1 ? t.mt / 2 : t.mt;
     return t;
 }
 
 template <int KH, int KW, int STRIDE, int PAD, int UPS, int WM, int WN, int MT, int KS, int NBUF, int PRO, int PREC>
 int launch_one(const ConvArgs& a, hipStream_t st) {
-    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC>;
+    using G = Geo<KH, KW, STRIDE, WM, MT, KS, NBUF, PREC, WM * WN * 64>;
     auto kern = conv_igemm_kernel<KH, KW, STRIDE, PAD, UPS, WM, WN, MT, KS, NBUF, PRO, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -368,7 +391,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     }
     const int CT = (a.Cout + 31) / 32;
     dim3 grid(a.B * a.tiles_x * a.tiles_y, (CT + WN - 1) / WN);
-    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
 
@@ -378,7 +401,8 @@ int launch_tile(const ConvArgs& a, int tile_id, hipStream_t st) {
     switch (tile_id) {
         case 0:  return launch_one<KH, KW, STRIDE, PAD, UPS, 1, 4, 8 / D, KS, NBUF, PRO, PREC>(a, st);
         case 1:  return launch_one<KH, KW, STRIDE, PAD, UPS, 2, 2, 4 / D, KS, NBUF, PRO, PREC>(a, st);
-        default: return launch_one<KH, KW, STRIDE, PAD, UPS, 1, 4, 4 / D, KS, NBUF, PRO, PREC>(a, st);
+        case 2:  return launch_one<KH, KW, STRIDE, PAD, UPS, 1, 4, 4 / D, KS, NBUF, PRO, PREC>(a, st);
+        default: return launch_one<KH, KW, STRIDE, PAD, UPS, 2, 4, 4 / D, KS, NBUF, PRO, PREC>(a, st);
     }
 }
 
@@ -398,7 +422,8 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 }  // namespace
 
 int conv_set_tuning(const char* key, int v) {
-    if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 2) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }
     return TEDM_EINVAL;
 }
 
@@ -408,7 +433,7 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : 1, ks = KH == 1 ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
-             ks, nbuf, pro, a.prec == TEDM_PREC_BF16 ? TEDM_PREC_BF16 : TEDM_PREC_BF16X3);
+             ks, nbuf, pro, a.prec);
 }
 
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {
@@ -436,5 +461,6 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     a.tiles_x = (a.Wo + 31) / 32;
     a.nk16 = Cin / 16;
     if (a.prec == TEDM_PREC_BF16) return launch_prec<TEDM_PREC_BF16>(a, KH, stride, ups, pro, tile_id, st);
+    if (a.prec == TEDM_PREC_FP16X2) return launch_prec<TEDM_PREC_FP16X2>(a, KH, stride, ups, pro, tile_id, st);
     return launch_prec<TEDM_PREC_BF16X3>(a, KH, stride, ups, pro, tile_id, st);
 }

@@ -353,23 +353,39 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 }
 
 // per-(sample, channel) 1/max(||.||_2 over pixels, 1e-12) from a (sum, sumsq) slab:
-// F.normalize(dim=-1) of models/unet_model.py:23,234.
-__global__ void colnorm_finalize_kernel(const float* __restrict__ slab, int E, int C, int B, float* __restrict__ inv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int n = i / C, c = i - n * C;
+// F.normalize(dim=-1) of models/unet_model.py:23,234.  One block per (sample, 64-channel group):
+// 4 waves split the slab entries, lanes own channels (coalesced), LDS combines the 4 partials.
+__global__ __launch_bounds__(256) void colnorm_finalize_kernel(const float* __restrict__ slab, int E, int C, int B,
+                                                               float* __restrict__ inv) {
+    __shared__ double part[4][64];
+    const int cg = (C + 63) / 64;
+    const int n = blockIdx.x / cg, c = (blockIdx.x - n * cg) * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
     double s = 0.0;
-    for (int e = 0; e < E; ++e) s += slab[(((size_t)n * E + e) * C + c) * 2 + 1];
-    inv[i] = 1.f / fmaxf((float)sqrt(s), 1e-12f);
+    if (c < C)
+        for (int e = w; e < E; e += 4) s += slab[(((size_t)n * E + e) * C + c) * 2 + 1];
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        inv[(size_t)n * C + c] = 1.f / fmaxf((float)sqrt(s), 1e-12f);
+    }
 }
 // per-(sample, channel) max over pixels from a max slab (k.softmax(dim=-1) stabiliser, :201)
-__global__ void colmax_finalize_kernel(const float* __restrict__ slab, int E, int C, int B, float* __restrict__ mx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int n = i / C, c = i - n * C;
+__global__ __launch_bounds__(256) void colmax_finalize_kernel(const float* __restrict__ slab, int E, int C, int B,
+                                                              float* __restrict__ mx) {
+    __shared__ float part[4][64];
+    const int cg = (C + 63) / 64;
+    const int n = blockIdx.x / cg, c = (blockIdx.x - n * cg) * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
     float m = -INFINITY;
-    for (int e = 0; e < E; ++e) m = fmaxf(m, slab[((size_t)n * E + e) * C + c]);
-    mx[i] = m;
+    if (c < C)
+        for (int e = w; e < E; e += 4) m = fmaxf(m, slab[((size_t)n * E + e) * C + c]);
+    part[w][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (w == 0 && c < C)
+        mx[(size_t)n * C + c] = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]),
+                                      fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
 }
 
 // nearest-resize one NHWC tap to (S,S) and scatter into the NCHW feature tensor
@@ -494,11 +510,11 @@ int op_final_conv(const float* x, const float* w, const float* bias, float* out,
 }
 
 int op_colnorm_finalize(const float* slab, int E, int C, int B, float* inv, hipStream_t st) {
-    hipLaunchKernelGGL(colnorm_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, slab, E, C, B, inv);
+    hipLaunchKernelGGL(colnorm_finalize_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 0, st, slab, E, C, B, inv);
     return LAUNCH_OK();
 }
 int op_colmax_finalize(const float* slab, int E, int C, int B, float* mx, hipStream_t st) {
-    hipLaunchKernelGGL(colmax_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, slab, E, C, B, mx);
+    hipLaunchKernelGGL(colmax_finalize_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 0, st, slab, E, C, B, mx);
     return LAUNCH_OK();
 }
 

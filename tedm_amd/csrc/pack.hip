@@ -10,7 +10,7 @@ namespace {
 //   wpk[ct][k16][tap][plane][lane][j],  lane = (h<<5)|r :  W[cout = ct*32+r][cin = k16*16+8h+j][tap]
 // (B[k = 8h+j][col = r], cdna guide section 3).  One 16-byte store per (fragment, lane, plane).
 __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int T, uint4* __restrict__ wpk,
-                                 long long total) {
+                                 long long total, int fp16) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -28,7 +28,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
         v[j] = cout < Cout ? w[((size_t)cout * Cin + cin) * T + tap] : 0.f;
     }
     uint4 hi, lo;
-    split8(v, hi, lo);
+    if (fp16) split8_f16(v, hi, lo); else split8(v, hi, lo);
     const size_t o = (((size_t)ct * nk16 + k16) * T + tap) * 2;
     wpk[(o + 0) * 64 + lane] = hi;
     wpk[(o + 1) * 64 + lane] = lo;
@@ -41,13 +41,13 @@ __global__ void copy_kernel(const float* __restrict__ s, float* __restrict__ d, 
 
 }  // namespace
 
-int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, hipStream_t st) {
+int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int fp16, hipStream_t st) {
     if (Cin % 16) return TEDM_EINVAL;
     const int T = KH * KW;
     const long long CT = (Cout + 31) / 32;
     const long long total = CT * (Cin / 16) * T * 64;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       w, Cout, Cin, T, (uint4*)wpk, total);
+                       w, Cout, Cin, T, (uint4*)wpk, total, fp16);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
 

@@ -157,6 +157,7 @@ struct tedm_unet {
     float* film_w = nullptr;   // [J][tdim]
     float* film_b = nullptr;   // [J]
     bool packed = false;
+    int prec = TEDM_PREC_BF16X3;       // arithmetic mode the packed weights are encoded for
     std::vector<Trace> trace;
 
     ~tedm_unet() {
@@ -560,12 +561,21 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
     if (!h->film_b && hipMalloc((void**)&h->film_b, (size_t)h->film_J * 4) != hipSuccess)
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
     for (ConvW* c : h->convs)
-        CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, st));
+        CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, h->prec == TEDM_PREC_FP16X2, st));
     for (ResPlan* r : h->resblocks) {
         CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.weight"), h->film_w + (size_t)r->film_off * h->tdim, (long long)2 * r->cout * h->tdim, st));
         CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.bias"), h->film_b + r->film_off, 2 * r->cout, st));
     }
     h->packed = true;
+    return TEDM_OK;
+}
+
+int tedm_unet_set_precision(tedm_unet* h, int prec) {
+    g_err[0] = 0;
+    if (!h) return fail(TEDM_EINVAL, "null handle");
+    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) h->packed = false;
+    h->prec = prec;
     return TEDM_OK;
 }
 
@@ -589,7 +599,9 @@ int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H
     if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
     CHECK(check_shape(h, B, H, W));
     const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
-    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2))
+        return fail(TEDM_ESTATE, "weights are packed for precision mode %d, forward asks for %d: call tedm_unet_set_precision + tedm_unet_pack", h->prec, prec);
     Arena A;
     const size_t mis = (size_t)((uintptr_t)workspace & 255);
     A.base = (char*)workspace + (mis ? 256 - mis : 0);
@@ -670,7 +682,7 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     void* wpk = nullptr;
     const size_t bytes = conv_packed_bytes(Cout, Cin, k * k);
     if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, st);
+    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec == TEDM_PREC_FP16X2, st);
     if (rc == TEDM_OK) {
         ConvArgs a{};
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;

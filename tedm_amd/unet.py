@@ -229,7 +229,9 @@ class Unet(nn.Module):
         optimizer step, .to())."""
         L = _lib.lib()
         tensors = self._native_tensors()
-        fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values())
+        if self.precision not in _lib.PREC_BY_NAME:
+            raise ValueError(f'unknown precision {self.precision!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
+        fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values()) + (self.precision,)
         if fp == self._fingerprint:
             return
         self._bound = []
@@ -246,6 +248,7 @@ class Unet(nn.Module):
                 tt = tt.float().contiguous()
             self._bound.append(tt)
             _lib.check(L.tedm_unet_set_param(self._handle, k.encode(), tt.data_ptr(), tt.numel()), f'set_param({k})')
+        _lib.check(L.tedm_unet_set_precision(self._handle, _lib.PREC_BY_NAME[self.precision]), 'set_precision')
         _lib.check(L.tedm_unet_pack(self._handle, stream_ptr), 'tedm_unet_pack')
         self._fingerprint = fp
 

@@ -241,19 +241,23 @@ def test_eps_vs_golden_256(dev, golden_dir, unet64):
 
 
 def test_precision_modes(dev, golden_dir, unet64):
-    """bf16x3 is the parity mode; plain bf16 is faster and must be reported with its own error."""
+    """bf16x3 is the parity mode.  The cheaper modes are opt-in and reported with their own error:
+    fp16x2 (2 MFMAs) sits just under the gate (measured 8.6e-4 at 32x256^2 -- no margin, not the
+    default), plain bf16 (1 MFMA) fails it by design."""
     g = np.load(golden_dir / 'eps_d64_s64.npz')
     x, t = torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev)
+    errs = {}
     try:
-        unet64.precision = 'bf16'
-        with torch.no_grad():
-            e1 = rel(unet64(x, t), g['eps'])
+        for mode in ('bf16', 'fp16x2', 'bf16x3'):
+            unet64.precision = mode
+            with torch.no_grad():
+                errs[mode] = rel(unet64(x, t), g['eps'])
     finally:
         unet64.precision = 'bf16x3'
-    with torch.no_grad():
-        e3 = rel(unet64(x, t), g['eps'])
-    print(f'eps rel-L2: bf16x3 {e3:.3e}   bf16 {e1:.3e}')
-    assert e3 < EPS_GATE and e3 < e1 < 0.1
+    print('eps rel-L2 by precision mode: ' + '  '.join(f'{k} {v:.3e}' for k, v in errs.items()))
+    assert errs['bf16x3'] < EPS_GATE / 10
+    assert errs['bf16x3'] < errs['fp16x2'] < errs['bf16'] < 0.1
+    assert errs['fp16x2'] < 3e-3
 
 
 def test_vs_oracle_ragged_shape(dev, unet64):
