@@ -59,6 +59,18 @@ def host_cores() -> int:
     return n
 
 
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary (tools/pmc_traffic.py:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
+    files = sorted((ROOT / 'profiles').glob('*pmc_traffic.json'))
+    if not files:
+        return None
+    try:
+        return json.loads(files[-1].read_text())['kernels'][kernel]['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -71,6 +83,7 @@ def main() -> None:
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
     ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
     ap.add_argument('--tile-narrow', type=int, default=None, help='tuning: conv tile id for Cout<128')
+    ap.add_argument('--tune', action='append', default=[], metavar='KEY=INT', help='tedm_set_tuning(KEY, INT)')
     args = ap.parse_args()
 
     import torch
@@ -99,6 +112,10 @@ def main() -> None:
         _lib.check(L.tedm_set_tuning(b'conv_tile_wide', args.tile_wide))
     if args.tile_narrow is not None:
         _lib.check(L.tedm_set_tuning(b'conv_tile_narrow', args.tile_narrow))
+
+    for kv in args.tune:
+        k, v = kv.split('=')
+        _lib.check(L.tedm_set_tuning(k.encode(), int(v)), f'tune {kv}')
 
     B, S, K, W = args.batch, args.size, args.steps, args.warmup
     cfg = Namespace(normalize=True, dim=64, dim_mults=(1, 2, 4, 8), channels=1, timesteps=1000,
@@ -179,7 +196,7 @@ def main() -> None:
             conv_ms = sum(e[2] for e in conv_prof)
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(name),
                 'launches': launches, 'avg_us': round(1e3 * ms / launches, 2),
                 'alg_gflop_per_launch': round(flops / launches / 1e9, 3),
                 'alg_mb_per_launch': round(byts / launches / 1e6, 3),

@@ -83,6 +83,8 @@ struct ConvArgs {
     float* stats;                  // STATS_SUMSQ: [B][E][Cout][2]   STATS_MAX: [B][E][Cout]
     int stats_mode;
     int tiles_x, tiles_y;          // spatial tiles per image
+    int ny;                        // cout-tile groups (filled by the launcher)
+    int xcd_order;                 // block-order policy (filled by the launcher)
     int nk16;                      // (C1+C2)/16
     int prec;                      // TEDM_PREC_*
 };

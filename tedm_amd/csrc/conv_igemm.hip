@@ -63,14 +63,29 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    int tile = blockIdx.x;
+    // Block order: 1-D grid over (spatial tile, cout-tile group).  Workgroups that read the SAME input
+    // tile (different cout groups) get block ids 8 apart -- the dispatcher deals blocks round-robin over
+    // the 8 XCDs, so they land on one XCD back to back and share the halo through its L2 (speed only).
     const int tpi = a.tiles_x * a.tiles_y;
+    const int ntile = a.B * tpi, ny = a.ny;
+    int tile, cty;
+    {
+        const int id = blockIdx.x;
+        if (a.xcd_order && (ntile & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            cty = slot % ny;
+            tile = (slot / ny) * 8 + xcd;
+        } else {
+            cty = id % ny;
+            tile = id / ny;
+        }
+    }
     const int n = tile / tpi;
     tile -= n * tpi;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int oy0 = ty * G::TR, ox0 = tx * 32;
     const int CT = (a.Cout + 31) >> 5;
-    const int ct = blockIdx.y * WN + wn;
+    const int ct = cty * WN + wn;
     const bool active = ct < CT;                              // wave-uniform
     const int Cin = a.C1 + a.C2;
     const int Hin = UPS ? a.H * 2 : a.H, Win = UPS ? a.W * 2 : a.W;
@@ -363,7 +378,8 @@ struct TileSel { int wm, wn, mt; };
 // stride-2 convs use half the rows (the halo doubles).
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
 int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
-int g_tile_narrow = 1;    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
+int g_tile_narrow = 1;
+int g_xcd_order = 1;      // 1: cout-tile groups of one input tile share an XCD (tedm_set_tuning("conv_xcd_order", v))    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
 
 inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : g_tile_narrow; }
 inline TileSel tile_geom(int id, int stride) {
@@ -390,8 +406,11 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int CT = (a.Cout + 31) / 32;
-    dim3 grid(a.B * a.tiles_x * a.tiles_y, (CT + WN - 1) / WN);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, a);
+    ConvArgs b = a;
+    b.ny = (CT + WN - 1) / WN;
+    b.xcd_order = g_xcd_order;
+    dim3 grid(a.B * a.tiles_x * a.tiles_y * b.ny);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, b);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
 
@@ -423,6 +442,7 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }
     return TEDM_EINVAL;
 }
