@@ -28,6 +28,14 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
                    float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream);
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
 
+/* LinearAttention core (models/unet_model.py:197-207) through the fused sweeps of linattn_fused.hip:
+ *   x (B,hw,C) fp32, PreNorm gain g (C), lnstats (B*hw,2) = (rstd, mean*rstd), wqkv_oihw (384,C,1,1);
+ *   outputs: kmax (B,128) = max over pixels of k, ctx (B,4,32,32) = softmax_n(k) v^T / hw,
+ *   o (B,hw,128) = ctx^T softmax_d(q) * 32^-0.5 (the tensor to_out consumes).  heads = 4, dim_head = 32.
+ * Synchronises the stream before returning (test helper). */
+int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* lnstats, const float* wqkv_oihw,
+                          int B, long long hw, float* kmax_out, float* ctx_out, float* o_out, int prec, void* stream);
+
 /* Tuning knobs (benchmark harness): "conv_tile_wide" = 0|1|2 selects the workgroup tile used for
  * convolutions with >= 128 output channels (conv_igemm.hip). */
 int tedm_set_tuning(const char* key, int value);

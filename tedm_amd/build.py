@@ -17,7 +17,7 @@ ROOT = PKG.parent
 CSRC = PKG / 'csrc'
 OBJ = CSRC / 'build'
 LIB = PKG / 'libtedm_hip.so'
-SOURCES = ['conv_igemm.hip', 'pack.hip', 'elementwise.hip', 'attention.hip', 'unet_host.hip']
+SOURCES = ['conv_igemm.hip', 'pack.hip', 'elementwise.hip', 'attention.hip', 'linattn_fused.hip', 'unet_host.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if force:
         for o in OBJ.glob('*.o'):
             o.unlink()
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -68,17 +68,15 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
 // pass 1 finalize: ctx[b][head][d][e] = sum_s ctx_p / (sum_s z_p[d] * hw)   (v / (h*w), :204)
 __global__ __launch_bounds__(256) void linattn_ctx_finalize_kernel(const float* __restrict__ part, int heads, int S,
                                                                    long long hw, float* __restrict__ ctx) {
-    const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-        const int d = i >> 5;
-        float c = 0.f, z = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float* cp = part + ((size_t)((size_t)b * S + s) * heads + head) * (1024 + 32);
-            c += cp[i];
-            z += cp[1024 + d];
-        }
-        ctx[(size_t)blockIdx.x * 1024 + i] = c / (z * (float)hw);
+    const int bh = blockIdx.x >> 2, b = bh / heads, head = bh - b * heads;      // 4 blocks per (sample, head)
+    const int i = (blockIdx.x & 3) * 256 + threadIdx.x, d = i >> 5;
+    float c = 0.f, z = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* cp = part + ((size_t)((size_t)b * S + s) * heads + head) * (1024 + 32);
+        c += cp[i];
+        z += cp[1024 + d];
     }
+    ctx[(size_t)bh * 1024 + i] = c / (z * (float)hw);
 }
 
 // linear attention, pass 2: o[n][head*32+e] = sum_d ctx[d][e] * softmax_d(q[n][:])[d] * 32^-0.5
@@ -247,7 +245,12 @@ int op_linattn_context(const float* qkv, const float* kmax, int B, long long hw,
     const long long waves = (long long)B * S * heads;
     hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, kmax, B, hw, heads,
                        S, pps, partial);
-    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    return LAUNCH_OK();
+}
+
+int op_linattn_ctx_finalize(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st) {
+    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
     return LAUNCH_OK();
 }
 

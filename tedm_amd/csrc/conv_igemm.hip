@@ -93,6 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
 
     // ---- per-thread staging geometry (identical for every channel chunk) ----------------
     int gp[G::NIT];        // source pixel index (n*H+sy)*W+sx, -1 = zero padding, -2 = no piece
+    int gpc[G::NIT];       // same, clamped into the image (what the unconditional loads read)
     int lofs[G::NIT];      // LDS byte offset of this piece inside a precision plane
     float ln_r[G::NIT], ln_m[G::NIT];
     const int piece = tid % (2 * KS);
@@ -100,18 +101,20 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     for (int it = 0; it < G::NIT; ++it) {
         const int i = tid + it * NTHR;
         const int pl = i / (2 * KS);
-        gp[it] = -2; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
+        gp[it] = -2; gpc[it] = n * a.H * a.W; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
         if (pl < G::HR * G::HC) {
             const int hy = pl / G::HC, hx = pl - hy * G::HC;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
             const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
-            gp[it] = valid ? (n * a.H + sy) * a.W + sx : -1;
+            const int syc = sy < 0 ? 0 : (sy >= a.H ? a.H - 1 : sy), sxc = sx < 0 ? 0 : (sx >= a.W ? a.W - 1 : sx);
+            gpc[it] = (n * a.H + syc) * a.W + sxc;
+            gp[it] = valid ? gpc[it] : -1;
             const int lpix = STRIDE == 1 ? pl
                 : ((hy & 1) * 2 + (hx & 1)) * G::PLANE2 + (hy >> 1) * G::HC2 + (hx >> 1);
             lofs[it] = lpix * G::PSTRIDE + piece * 16;
-            if (PRO == PRO_LN && valid) {
-                const float2 s = *(const float2*)(a.pro_b + (size_t)gp[it] * 2);
+            if (PRO == PRO_LN) {
+                const float2 s = *(const float2*)(a.pro_b + (size_t)gpc[it] * 2);
                 ln_r[it] = s.x; ln_m[it] = s.y;
             }
         }
@@ -127,15 +130,13 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
         else           { src = a.x2; cs = a.C2; ch = cb - a.C1; }
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
-            if (gp[it] >= 0) {
-                const float4* p = (const float4*)(src + (size_t)gp[it] * cs + ch);
-                const float4 v0 = p[0], v1 = p[1];
-                raw[it][0] = v0.x; raw[it][1] = v0.y; raw[it][2] = v0.z; raw[it][3] = v0.w;
-                raw[it][4] = v1.x; raw[it][5] = v1.y; raw[it][6] = v1.z; raw[it][7] = v1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) raw[it][j] = 0.f;
-            }
+            // unconditional loads (padding / unused pieces read the tile's clamped pixel gpc[it] and are
+            // zeroed when staged): VMEM inside lane-divergent branches mis-synchronised on gfx950, see
+            // linattn_fused.hip
+            const float4* p = (const float4*)(src + (size_t)gpc[it] * cs + ch);
+            const float4 v0 = p[0], v1 = p[1];
+            raw[it][0] = v0.x; raw[it][1] = v0.y; raw[it][2] = v0.z; raw[it][3] = v0.w;
+            raw[it][4] = v1.x; raw[it][5] = v1.y; raw[it][6] = v1.z; raw[it][7] = v1.w;
         }
         if (PRO == PRO_GN) {
             const float4* qa = (const float4*)(a.pro_a + (size_t)n * Cin + cb);
@@ -162,11 +163,9 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float x = raw[it][j];
-                if (gp[it] >= 0) {
-                    if (PRO == PRO_GN) x = silu_f(fmaf(pa[j], x, pb[j]));
-                    else if (PRO == PRO_LN) x = pa[j] * (x * ln_r[it] - ln_m[it]);
-                }
-                v[j] = x;
+                if (PRO == PRO_GN) x = silu_f(fmaf(pa[j], x, pb[j]));
+                else if (PRO == PRO_LN) x = pa[j] * (x * ln_r[it] - ln_m[it]);
+                v[j] = gp[it] >= 0 ? x : 0.f;              // zero padding applies AFTER the prologue
             }
             if (PREC == TEDM_PREC_FP16X2) {
                 *(uint4*)(base + lofs[it]) = cvt8_f16(v);

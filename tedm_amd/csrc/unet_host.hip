@@ -139,6 +139,7 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
+int g_la_fused = 1;   // tedm_set_tuning("la_fused", 0|1): fused linear-attention sweeps vs qkv-tensor path
 
 }  // namespace
 
@@ -352,20 +353,44 @@ struct Fwd {
     int linattn(const AttnPlan& a, const float* x, const float* ln, int H, int W, float* out_buf, float** out) {
         const long long hw = (long long)H * W, P = (long long)B * hw;
         const int C = a.C, C3 = 3 * u->hidden, heads = u->cfg.heads;
-        float* qkv = A->alloc((size_t)P * C3);
-        const int E = conv_stats_entries(1, 1, C3, H, W);
-        float* slab = A->alloc((size_t)B * E * C3);
-        CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_MAX));
-        float* kmax = A->alloc((size_t)B * C3);
-        OP("colmax_finalize", 0.0, 4.0 * B * E * C3, op_colmax_finalize(slab, E, C3, B, kmax, st));
-        A->release(slab);
-        float* part = A->alloc(la_ctx_partial_floats(B, heads, hw));
-        float* ctx = A->alloc((size_t)B * heads * 1024);
-        OP("linattn_context", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
-        A->release(part); A->release(kmax);
-        float* o = A->alloc((size_t)P * u->hidden);
-        OP("linattn_out", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_out(qkv, ctx, B, hw, heads, o, st));
-        A->release(qkv); A->release(ctx);
+        float* o;
+        if (g_la_fused && heads == 4 && C % 32 == 0) {
+            // three recompute sweeps over x (linattn_fused.hip); the qkv tensor is never materialised
+            const int S = la_fused_wgs_per_image(0, hw), S2 = la_fused_wgs_per_image(1, hw);
+            const float* gpre = u->P(a.pre + ".fn.norm.g");
+            const double pf = 2.0 * P * C, pb = 4.0 * P * C;
+            float* kpart = A->alloc((size_t)B * S * u->hidden);
+            float* kmax = A->alloc((size_t)B * u->hidden);
+            OP("linattn_fused<kmax>", pf * u->hidden, pb,
+               op_linattn_fused(0, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st));
+            OP("colmax_finalize", 0.0, 4.0 * B * S * u->hidden, op_colmax_finalize(kpart, S, u->hidden, B, kmax, st));
+            A->release(kpart);
+            float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 32));
+            float* ctx = A->alloc((size_t)B * heads * 1024);
+            OP("linattn_fused<ctx>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
+               op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, prec, st));
+            OP("linattn_ctx_finalize", 0.0, 4.0 * B * S2 * heads * 1056, op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx, st));
+            A->release(cpart); A->release(kmax);
+            o = A->alloc((size_t)P * u->hidden);
+            OP("linattn_fused<qout>", pf * u->hidden + 2048.0 * P * heads, pb + 4.0 * P * u->hidden,
+               op_linattn_fused(2, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx, o, prec, st));
+            A->release(ctx);
+        } else {
+            float* qkv = A->alloc((size_t)P * C3);
+            const int E = conv_stats_entries(1, 1, C3, H, W);
+            float* slab = A->alloc((size_t)B * E * C3);
+            CHECK(conv(a.qkv, x, C, nullptr, 0, H, W, H, W, qkv, 1, 0, PRO_LN, u->P(a.pre + ".fn.norm.g"), ln, nullptr, nullptr, nullptr, slab, STATS_MAX));
+            float* kmax = A->alloc((size_t)B * C3);
+            OP("colmax_finalize", 0.0, 4.0 * B * E * C3, op_colmax_finalize(slab, E, C3, B, kmax, st));
+            A->release(slab);
+            float* part = A->alloc(la_ctx_partial_floats(B, heads, hw));
+            float* ctx = A->alloc((size_t)B * heads * 1024);
+            OP("linattn_context", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
+            A->release(part); A->release(kmax);
+            o = A->alloc((size_t)P * u->hidden);
+            OP("linattn_out", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_out(qkv, ctx, B, hw, heads, o, st));
+            A->release(qkv); A->release(ctx);
+        }
         float* z = A->alloc((size_t)P * C);
         CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, z, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, STATS_NONE));
         A->release(o);
@@ -662,6 +687,7 @@ int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, dou
 int tedm_set_tuning(const char* key, int value) {
     g_err[0] = 0;
     if (!key) return fail(TEDM_EINVAL, "null key");
+    if (!strcmp(key, "la_fused") && (value == 0 || value == 1)) { g_la_fused = value; return TEDM_OK; }
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
 }
@@ -698,6 +724,29 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     (void)hipStreamSynchronize(st);
     (void)hipFree(wpk);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d failed (%d)", rc);
+}
+
+// ---- op-level entry point (tests): the three fused linear-attention sweeps + their finalizers ----
+int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* lnstats, const float* wqkv_oihw,
+                          int B, long long hw, float* kmax_out, float* ctx_out, float* o_out, int prec, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int heads = 4, hidden = 128;
+    if (!x || !g || !lnstats || !wqkv_oihw || !kmax_out || !ctx_out || !o_out || C % 32) return fail(TEDM_EINVAL, "bad argument");
+    const int S = la_fused_wgs_per_image(0, hw), S2 = la_fused_wgs_per_image(1, hw);
+    void* wpk = nullptr; float *kpart = nullptr, *cpart = nullptr;
+    const size_t wbytes = conv_packed_bytes(3 * hidden, C, 1);
+    if (hipMalloc(&wpk, wbytes) != hipSuccess || hipMalloc((void**)&kpart, (size_t)B * S * hidden * 4) != hipSuccess ||
+        hipMalloc((void**)&cpart, (size_t)B * S2 * heads * 1056 * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    int rc = pack_conv_weights(wqkv_oihw, 3 * hidden, C, 1, 1, wpk, prec == TEDM_PREC_FP16X2, st);
+    if (rc == TEDM_OK) rc = op_linattn_fused(0, x, C, g, lnstats, wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st);
+    if (rc == TEDM_OK) rc = op_colmax_finalize(kpart, S, hidden, B, kmax_out, st);
+    if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, kmax_out, cpart, nullptr, nullptr, prec, st);
+    if (rc == TEDM_OK) rc = op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx_out, st);
+    if (rc == TEDM_OK) rc = op_linattn_fused(2, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx_out, o_out, prec, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(wpk); (void)hipFree(kpart); (void)hipFree(cpart);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_linattn_fused failed (%d)", rc);
 }
 
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo) { return conv_stats_entries(k, stride, Cout, Ho, Wo); }

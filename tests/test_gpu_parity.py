@@ -162,6 +162,42 @@ def test_conv_prologues_and_epilogues(lib, dev):
     assert rel(out, ref) < KERNEL_TOL
 
 
+@pytest.mark.parametrize('B,hw,Cc', [(3, 1000, 64), (32, 2048, 128), (8, 16384, 64)],
+                         ids=['ragged', '512-workgroups', 'multi-tile'])
+def test_linattn_fused_sweeps(lib, dev, B, hw, Cc):
+    """LinearAttention core (unet_model.py:197-207) through the three recompute sweeps, against an fp64
+    restatement; also bitwise reproducibility with more workgroups than CUs (regression: lane-divergent
+    VMEM blocks once staged stale registers whenever two workgroups shared a CU)."""
+    from tedm_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, hw, Cc, generator=g)
+    gain = 1 + 0.1 * torch.randn(Cc, generator=g)
+    w = torch.randn(384, Cc, generator=g) / Cc ** 0.5
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    stats = torch.cat((rstd, mean * rstd), -1).reshape(-1, 2).contiguous()
+    xd, gd, sd, wd = x.to(dev), gain.to(dev), stats.to(dev), w.reshape(384, Cc, 1, 1).contiguous().to(dev)
+    outs = []
+    for _ in range(2):
+        kmax = torch.empty(B, 128, device=dev)
+        ctx = torch.empty(B, 4, 32, 32, device=dev)
+        o = torch.empty(B, hw, 128, device=dev)
+        _lib.check(lib.tedm_op_linattn_fused(xd.data_ptr(), Cc, gd.data_ptr(), sd.data_ptr(), wd.data_ptr(), B, hw,
+                                             kmax.data_ptr(), ctx.data_ptr(), o.data_ptr(), 0,
+                                             torch.cuda.current_stream(dev).cuda_stream), 'tedm_op_linattn_fused')
+        outs.append((kmax.cpu(), ctx.cpu(), o.cpu()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    qkv = ((x - mean) * rstd * gain).double() @ w.double().t()
+    hd = lambda t: t.reshape(B, hw, 4, 32).permute(0, 2, 3, 1)           # b h d n
+    q, k, v = hd(qkv[..., :128]), hd(qkv[..., 128:256]), hd(qkv[..., 256:])
+    ctx_ref = torch.einsum('bhdn,bhen->bhde', k.softmax(-1), v / hw)
+    o_ref = torch.einsum('bhde,bhdn->bhen', ctx_ref, q.softmax(-2) * 32 ** -0.5).permute(0, 3, 1, 2).reshape(B, hw, 128)
+    assert rel(outs[0][0], k.amax(-1).reshape(B, 128)) < KERNEL_TOL
+    assert rel(outs[0][1], ctx_ref) < KERNEL_TOL
+    assert rel(outs[0][2], o_ref) < KERNEL_TOL
+
+
 # ------------------------------------------------------------------------------------------------
 def make_unet(dim, seed, dev):
     from tedm_amd import Unet, load_synth_weights
