@@ -71,6 +71,34 @@ def pmc_traffic(kernel: str):
         return None
 
 
+def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):
+    """BASELINE config 3: multi-timestep feature extraction (models/datasetDM_model.py:67-83), steps
+    [50,200,400,600,800] (config.py:78), B images per GPU -> (B, 960*5, S, S) fp32 on the device."""
+    import torch
+    from tedm_amd import DatasetDM
+    steps = [50, 200, 400, 600, 800]
+    ddm = DatasetDM(Namespace(normalize=True, dim=64, saved_diffusion_model='/nonexistent', verbose=False, device='cuda',
+                              t_steps_to_save=steps, max_images_per_forward=64))
+    ddm.diffusion_model = dm
+    ddm = ddm.to(dev).eval()
+    B, S = x0.shape[0], x0.shape[-1]
+
+    def step():
+        return ddm.extract_features(x0, noise=noise)
+    elapsed, feats = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'feature-extract images/sec @256x256, 5 timesteps (DatasetDM.extract_features)',
+            'value': round(world * B * args.steps / elapsed, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
+            'config': {'workload': f'DatasetDM.extract_features, {B}x1x{S}x{S} per GPU, t_steps={steps} (BASELINE configs[2])',
+                       'feature_tensor': list(feats.shape), 'unet_forwards_per_image': len(steps)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -79,6 +107,8 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
+    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract'],
+                    help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
     ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
@@ -89,21 +119,14 @@ def main() -> None:
     import torch
     from tedm_amd import DiffusionModel, _lib, load_synth_weights
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from tedm_amd import dp
+    world, rank, local = dp.env_world()
     if world != args.gpus:
         if rank == 0:
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    dist = dp.init('nccl') if world > 1 else None
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the HIP path has no CPU fallback)'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
@@ -134,11 +157,11 @@ def main() -> None:
         x_t = dm._q_sample(x0, t, noise, normalize=True)
         return dm.model(x_t, t)
 
+    if args.mode == 'extract':
+        return bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise)
+
     def sync_all():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        dp.barrier(dist, dev)
 
     with torch.no_grad():
         for _ in range(W):
@@ -154,10 +177,7 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         L.tedm_profile_enable(0)
         conv_prof = _lib.profile_entries()
-        if dist is not None:
-            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            elapsed = float(el.item())
+        elapsed = dp.max_over_ranks(dist, elapsed, dev)
 
         breakdown = None
         if args.breakdown and rank == 0:

@@ -85,6 +85,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;          // spatial tiles per image
     int ny;                        // cout-tile groups (filled by the launcher)
     int xcd_order;                 // block-order policy (filled by the launcher)
+    int tpw;                       // spatial tiles per workgroup (filled by the launcher)
     int nk16;                      // (C1+C2)/16
     int prec;                      // TEDM_PREC_*
 };

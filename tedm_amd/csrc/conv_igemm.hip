@@ -63,62 +63,69 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    // Block order: 1-D grid over (spatial tile, cout-tile group).  Workgroups that read the SAME input
-    // tile (different cout groups) get block ids 8 apart -- the dispatcher deals blocks round-robin over
-    // the 8 XCDs, so they land on one XCD back to back and share the halo through its L2 (speed only).
+    // Block order: 1-D grid over (group of a.tpw consecutive spatial tiles, cout-tile group).  Workgroups
+    // that read the SAME input tiles (different cout groups) get block ids 8 apart -- the dispatcher deals
+    // blocks round-robin over the 8 XCDs, so they land on one XCD back to back and share the halo through
+    // its L2 (speed only).  A workgroup walks its tiles with the (tile, chunk) loop flattened: the first
+    // chunk of the next tile is in flight while the current tile's epilogue stores.
     const int tpi = a.tiles_x * a.tiles_y;
     const int ntile = a.B * tpi, ny = a.ny;
-    int tile, cty;
+    const int nsuper = (ntile + a.tpw - 1) / a.tpw;
+    int super, cty;
     {
         const int id = blockIdx.x;
-        if (a.xcd_order && (ntile & 7) == 0) {
+        if (a.xcd_order && (nsuper & 7) == 0) {
             const int xcd = id & 7, slot = id >> 3;
             cty = slot % ny;
-            tile = (slot / ny) * 8 + xcd;
+            super = (slot / ny) * 8 + xcd;
         } else {
             cty = id % ny;
-            tile = id / ny;
+            super = id / ny;
         }
     }
-    const int n = tile / tpi;
-    tile -= n * tpi;
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * G::TR, ox0 = tx * 32;
+    const int tile_beg = super * a.tpw;
+    const int tile_cnt = (tile_beg + a.tpw <= ntile) ? a.tpw : ntile - tile_beg;
     const int CT = (a.Cout + 31) >> 5;
     const int ct = cty * WN + wn;
     const bool active = ct < CT;                              // wave-uniform
     const int Cin = a.C1 + a.C2;
     const int Hin = UPS ? a.H * 2 : a.H, Win = UPS ? a.W * 2 : a.W;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
 
-    // ---- per-thread staging geometry (identical for every channel chunk) ----------------
-    int gp[G::NIT];        // source pixel index (n*H+sy)*W+sx, -1 = zero padding, -2 = no piece
-    int gpc[G::NIT];       // same, clamped into the image (what the unconditional loads read)
+    // ---- per-thread staging geometry of the tile being STAGED (same for all its channel chunks) ----
+    int gp[G::NIT];        // >= 0: valid source pixel, -1 = zero padding, -2 = no piece
+    int gpc[G::NIT];       // source pixel index clamped into the image (what the unconditional loads read)
     int lofs[G::NIT];      // LDS byte offset of this piece inside a precision plane
     float ln_r[G::NIT], ln_m[G::NIT];
     const int piece = tid % (2 * KS);
+    int ns = 0;            // image of the tile being staged
+    auto setup_tile = [&](int tl) {
+        ns = tl / tpi;
+        const int trem = tl - ns * tpi;
+        const int tys = trem / a.tiles_x, txs = trem - tys * a.tiles_x;
+        const int iy0 = tys * G::TR * STRIDE - PAD, ix0 = txs * 32 * STRIDE - PAD;
 #pragma unroll
-    for (int it = 0; it < G::NIT; ++it) {
-        const int i = tid + it * NTHR;
-        const int pl = i / (2 * KS);
-        gp[it] = -2; gpc[it] = n * a.H * a.W; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
-        if (pl < G::HR * G::HC) {
-            const int hy = pl / G::HC, hx = pl - hy * G::HC;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-            const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
-            const int syc = sy < 0 ? 0 : (sy >= a.H ? a.H - 1 : sy), sxc = sx < 0 ? 0 : (sx >= a.W ? a.W - 1 : sx);
-            gpc[it] = (n * a.H + syc) * a.W + sxc;
-            gp[it] = valid ? gpc[it] : -1;
-            const int lpix = STRIDE == 1 ? pl
-                : ((hy & 1) * 2 + (hx & 1)) * G::PLANE2 + (hy >> 1) * G::HC2 + (hx >> 1);
-            lofs[it] = lpix * G::PSTRIDE + piece * 16;
-            if (PRO == PRO_LN) {
-                const float2 s = *(const float2*)(a.pro_b + (size_t)gpc[it] * 2);
-                ln_r[it] = s.x; ln_m[it] = s.y;
+        for (int it = 0; it < G::NIT; ++it) {
+            const int i = tid + it * NTHR;
+            const int pl = i / (2 * KS);
+            gp[it] = -2; gpc[it] = ns * a.H * a.W; lofs[it] = 0; ln_r[it] = 0.f; ln_m[it] = 0.f;
+            if (pl < G::HR * G::HC) {
+                const int hy = pl / G::HC, hx = pl - hy * G::HC;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+                const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+                const int syc = sy < 0 ? 0 : (sy >= a.H ? a.H - 1 : sy), sxc = sx < 0 ? 0 : (sx >= a.W ? a.W - 1 : sx);
+                gpc[it] = (ns * a.H + syc) * a.W + sxc;
+                gp[it] = valid ? gpc[it] : -1;
+                const int lpix = STRIDE == 1 ? pl
+                    : ((hy & 1) * 2 + (hx & 1)) * G::PLANE2 + (hy >> 1) * G::HC2 + (hx >> 1);
+                lofs[it] = lpix * G::PSTRIDE + piece * 16;
+                if (PRO == PRO_LN) {
+                    const float2 st2 = *(const float2*)(a.pro_b + (size_t)gpc[it] * 2);
+                    ln_r[it] = st2.x; ln_m[it] = st2.y;
+                }
             }
         }
-    }
+    };
 
     float raw[G::NIT][8];
     float pa[8], pb[8];
@@ -130,17 +137,16 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
         else           { src = a.x2; cs = a.C2; ch = cb - a.C1; }
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
-            // unconditional loads (padding / unused pieces read the tile's clamped pixel gpc[it] and are
-            // zeroed when staged): VMEM inside lane-divergent branches mis-synchronised on gfx950, see
-            // linattn_fused.hip
+            // unconditional loads (padding / unused pieces read the clamped pixel gpc[it] and are zeroed when
+            // staged): VMEM inside lane-divergent branches mis-synchronised on gfx950, see linattn_fused.hip
             const float4* p = (const float4*)(src + (size_t)gpc[it] * cs + ch);
             const float4 v0 = p[0], v1 = p[1];
             raw[it][0] = v0.x; raw[it][1] = v0.y; raw[it][2] = v0.z; raw[it][3] = v0.w;
             raw[it][4] = v1.x; raw[it][5] = v1.y; raw[it][6] = v1.z; raw[it][7] = v1.w;
         }
         if (PRO == PRO_GN) {
-            const float4* qa = (const float4*)(a.pro_a + (size_t)n * Cin + cb);
-            const float4* qb = (const float4*)(a.pro_b + (size_t)n * Cin + cb);
+            const float4* qa = (const float4*)(a.pro_a + (size_t)ns * Cin + cb);
+            const float4* qb = (const float4*)(a.pro_b + (size_t)ns * Cin + cb);
             const float4 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
             pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w;
             pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
@@ -179,16 +185,11 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     };
 
     f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-
     const uint4* wq = (const uint4*)a.wpk;
     const int lane_a = (STRIDE == 1 ? (wm * MT * G::HC + r) : (wm * MT * G::HC2 + r)) * G::PSTRIDE + h * 16;
     const int NC = a.nk16 / KS;
 
-    // Weight fragments are fetched one tap-column group (all ky of one kx) AHEAD of the MFMAs that
+    // Weight fragments are fetched one or two tap-column groups (all ky of one kx) AHEAD of the MFMAs that
     // consume them; the group's registers are bq[set].  Sets are indexed statically (kx, or the chunk
     // parity for 1x1) so they stay in VGPRs.
     constexpr int NSET = KW > 1 ? KW : 2;
@@ -247,123 +248,141 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
                 }
     };
 
-    // one staged chunk: MFMAs of chunk c from LDS buffer `buf`; weight groups are fetched PD groups
-    // ahead (3x3 / 4x4: two tap columns ~ 2 x 36 MFMAs of cover for the L2 latency; 1x1: one chunk).
-    constexpr int PD = KW > 1 ? 2 : 1;
-    auto chunk_body = [&](int c, int buf, auto par) {
-        constexpr int PAR = decltype(par)::value;             // chunk parity (used by the 1x1 sets)
+    // ---- epilogue of one finished tile ------------------------------------------------------------
+    // acc[mt][i]: pixel column ox0 + (i&3) + 8*(i>>2) + 4*h of output row oy0 + wm*MT + mt, channel
+    // ct*32 + r.  A store instruction therefore writes two 128-B segments (32 channels x 2 pixels).
+    const int cout = ct * 32 + r;
+    const bool cok = active && cout < a.Cout;
+    const float bias = (a.bias && cok) ? a.bias[cout] : 0.f;
+    const int cstride = a.Cout;
+    auto epilogue = [&](int tl) {
+        if (!active) return;
+        const int n = tl / tpi;
+        const int trem = tl - n * tpi;
+        const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+        const int oy0 = ty * G::TR, ox0 = tx * 32;
+        float aa = 1.f, ab = 0.f;
+        if (a.add_a && cok) { aa = a.add_a[(size_t)n * a.Cout + cout]; ab = a.add_b[(size_t)n * a.Cout + cout]; }
+        float s1 = 0.f, s2 = 0.f, smax = -INFINITY;
+        const bool full_cols = ox0 + 32 <= a.Wo;               // block-uniform
+        auto emit = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;       // 0: no addend, 1: plain addend, 2: silu(aa*add+ab)
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            if (KW > 1) {
-                const int kx2 = (kx + PD) % KW, c2 = c + (kx + PD) / KW;
-                if (c2 < NC) load_b(c2, kx2, bq[kx2]);
-                compute_kx(buf, kx, bq[kx]);
-            } else {
-                if (c + 1 < NC) load_b(c + 1, 0, bq[PAR ^ 1]);
-                compute_kx(buf, 0, bq[PAR]);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int oy = oy0 + wm * MT + mt;
+                if (oy >= a.Ho) continue;                      // wave-uniform
+                const size_t rowbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox0 + 4 * h) * cstride + cout;
+                float* op = a.out + rowbase;
+                const float* ap = MODE ? a.add + rowbase : nullptr;
+                if (full_cols) {
+                    if (!cok) continue;
+                    float ad[16];
+                    if (MODE) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) ad[i] = ap[((i & 3) + 8 * (i >> 2)) * cstride];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float v = acc[mt][i] + bias;
+                        if (MODE == 1) v += ad[i];
+                        if (MODE == 2) v += silu_f(fmaf(aa, ad[i], ab));
+                        op[((i & 3) + 8 * (i >> 2)) * cstride] = v;
+                        s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dx = (i & 3) + 8 * (i >> 2);
+                        if (ox0 + 4 * h + dx < a.Wo && cok) {
+                            float v = acc[mt][i] + bias;
+                            if (MODE) {
+                                float t = ap[dx * cstride];
+                                if (MODE == 2) t = silu_f(fmaf(aa, t, ab));
+                                v += t;
+                            }
+                            op[dx * cstride] = v;
+                            s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                        }
+                    }
+                }
+            }
+        };
+        if (!a.add) emit(std::integral_constant<int, 0>{});
+        else if (!a.add_a) emit(std::integral_constant<int, 1>{});
+        else emit(std::integral_constant<int, 2>{});
+
+        if (a.stats_mode != STATS_NONE) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); smax = fmaxf(smax, __shfl_xor(smax, 32));
+            if (h == 0 && cok) {
+                const int E = tpi * WM;
+                const int e = (ty * a.tiles_x + tx) * WM + wm;
+                if (a.stats_mode == STATS_SUMSQ) {
+                    float2* p = (float2*)a.stats + ((size_t)n * E + e) * a.Cout + cout;
+                    *p = make_float2(s1, s2);
+                } else {
+                    a.stats[((size_t)n * E + e) * a.Cout + cout] = smax;
+                }
             }
         }
     };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    };
 
     if (NBUF == 2) {
+        // weight groups are fetched PD groups ahead (two tap columns ~ 2 x 36 MFMAs of cover for the L2
+        // latency); the sequence simply wraps to chunk 0 at a tile boundary (same weights, next tile)
+        constexpr int PD = KW > 1 ? 2 : 1;
+        const int total = tile_cnt * NC;                      // flattened (tile, chunk) iterations
+        auto chunk_body = [&](int c, int buf, bool more) {
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int kx2 = (kx + PD) % KW;
+                int c2 = c + (kx + PD) / KW;
+                const bool wrap = c2 >= NC;
+                if (wrap) c2 -= NC;
+                if (!wrap || more) load_b(c2, kx2, bq[kx2 % NSET]);
+                compute_kx(buf, kx, bq[kx % NSET]);
+            }
+        };
+        setup_tile(tile_beg);
         load_b(0, 0, bq[0]);
-        if (KW > 1) load_b(0, 1, bq[1]);
+        if (KW > 1) load_b(0, 1 % KW, bq[1 % NSET]);
         issue_loads(0);
         write_lds(0);
         __syncthreads();
-        auto step = [&](int c, auto par) {
-            if (c + 1 < NC) issue_loads(c + 1);
-            chunk_body(c, c & 1, par);
-            if (c + 1 < NC) write_lds((c + 1) & 1);
+        int c = 0, tl = tile_beg;
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            const bool last_chunk = c == NC - 1;
+            if (more) {
+                if (last_chunk) setup_tile(tl + 1);           // the next iteration stages a new tile
+                issue_loads(last_chunk ? 0 : c + 1);
+            }
+            if (c == 0) zero_acc();
+            chunk_body(c, it & 1, !last_chunk || more);
+            if (more) write_lds((it + 1) & 1);
             __syncthreads();
-        };
-        for (int c = 0; c < NC; c += 2) {
-            step(c, std::integral_constant<int, 0>{});
-            if (c + 1 < NC) step(c + 1, std::integral_constant<int, 1>{});
+            if (last_chunk) { epilogue(tl); ++tl; c = 0; } else ++c;
         }
     } else {
         // single LDS buffer (1x1, HBM-bound): keep registers low so 3-4 workgroups share a CU and
         // overlap each other's load / MFMA phases; the chunk's weights travel with its activations.
-        for (int c = 0; c < NC; ++c) {
-            load_b(c, 0, bq[0]);
-            issue_loads(c);
-            __syncthreads();
-            write_lds(0);
-            __syncthreads();
-            compute_kx(0, 0, bq[0]);
-        }
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------
-    // acc[mt][i]: pixel column ox0 + (i&3) + 8*(i>>2) + 4*h of output row oy0 + wm*MT + mt, channel
-    // ct*32 + r.  A store instruction therefore writes two 128-B segments (32 channels x 2 pixels).
-    if (!active) return;
-    const int cout = ct * 32 + r;
-    const bool cok = cout < a.Cout;
-    const float bias = (a.bias && cok) ? a.bias[cout] : 0.f;
-    float aa = 1.f, ab = 0.f;
-    if (a.add_a && cok) { aa = a.add_a[(size_t)n * a.Cout + cout]; ab = a.add_b[(size_t)n * a.Cout + cout]; }
-    float s1 = 0.f, s2 = 0.f, smax = -INFINITY;
-    const bool full_cols = ox0 + 32 <= a.Wo;                   // block-uniform
-    const int cstride = a.Cout;
-
-    auto emit = [&](auto mode) {
-        constexpr int MODE = decltype(mode)::value;           // 0: no addend, 1: plain addend, 2: silu(aa*add+ab)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int oy = oy0 + wm * MT + mt;
-            if (oy >= a.Ho) continue;                          // wave-uniform
-            const size_t rowbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox0 + 4 * h) * cstride + cout;
-            float* op = a.out + rowbase;
-            const float* ap = MODE ? a.add + rowbase : nullptr;
-            if (full_cols) {
-                if (!cok) continue;
-                float ad[16];
-                if (MODE) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) ad[i] = ap[((i & 3) + 8 * (i >> 2)) * cstride];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = acc[mt][i] + bias;
-                    if (MODE == 1) v += ad[i];
-                    if (MODE == 2) v += silu_f(fmaf(aa, ad[i], ab));
-                    op[((i & 3) + 8 * (i >> 2)) * cstride] = v;
-                    s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int dx = (i & 3) + 8 * (i >> 2);
-                    if (ox0 + 4 * h + dx < a.Wo && cok) {
-                        float v = acc[mt][i] + bias;
-                        if (MODE) {
-                            float t = ap[dx * cstride];
-                            if (MODE == 2) t = silu_f(fmaf(aa, t, ab));
-                            v += t;
-                        }
-                        op[dx * cstride] = v;
-                        s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
-                    }
-                }
+        for (int tl = tile_beg; tl < tile_beg + tile_cnt; ++tl) {
+            setup_tile(tl);
+            zero_acc();
+            for (int c = 0; c < NC; ++c) {
+                load_b(c, 0, bq[0]);
+                issue_loads(c);
+                __syncthreads();
+                write_lds(0);
+                __syncthreads();
+                compute_kx(0, 0, bq[0]);
             }
-        }
-    };
-    if (!a.add) emit(std::integral_constant<int, 0>{});
-    else if (!a.add_a) emit(std::integral_constant<int, 1>{});
-    else emit(std::integral_constant<int, 2>{});
-
-    if (a.stats_mode != STATS_NONE) {
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); smax = fmaxf(smax, __shfl_xor(smax, 32));
-        if (h == 0 && cok) {
-            const int E = tpi * WM;
-            const int e = (ty * a.tiles_x + tx) * WM + wm;
-            if (a.stats_mode == STATS_SUMSQ) {
-                float2* p = (float2*)a.stats + ((size_t)n * E + e) * a.Cout + cout;
-                *p = make_float2(s1, s2);
-            } else {
-                a.stats[((size_t)n * E + e) * a.Cout + cout] = smax;
-            }
+            epilogue(tl);
         }
     }
 }
@@ -378,6 +397,7 @@ struct TileSel { int wm, wn, mt; };
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
 int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
 int g_tile_narrow = 1;
+int g_tpw_max = 1;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
 int g_xcd_order = 1;      // 1: cout-tile groups of one input tile share an XCD (tedm_set_tuning("conv_xcd_order", v))    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
 
 inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : g_tile_narrow; }
@@ -408,7 +428,13 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     b.ny = (CT + WN - 1) / WN;
     b.xcd_order = g_xcd_order;
-    dim3 grid(a.B * a.tiles_x * a.tiles_y * b.ny);
+    // tiles per workgroup: keep >= ~2048 workgroups in the grid, at most g_tpw_max tiles each (NBUF==2 path)
+    const int ntile = a.B * a.tiles_x * a.tiles_y;
+    int tpw = NBUF == 2 ? (int)(((long long)ntile * b.ny) / 2048) : 1;
+    if (tpw > g_tpw_max) tpw = g_tpw_max;
+    if (tpw < 1) tpw = 1;
+    b.tpw = tpw;
+    dim3 grid(((ntile + tpw - 1) / tpw) * b.ny);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, b);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
@@ -441,6 +467,7 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }
     return TEDM_EINVAL;

@@ -404,6 +404,49 @@ __global__ void tap_to_features_kernel(const float* __restrict__ tap, int h, int
     }
 }
 
+// Integer-factor variant (the TEDM case: S / h in {1,2,4,8}): a block takes 32 source pixels of one row
+// x 64 channels, transposes them through LDS, and writes every (channel, replicated row) as contiguous
+// float4 runs of the NCHW feature tensor -- reads and writes are both fully coalesced.
+__global__ __launch_bounds__(256) void tap_to_features_tiled_kernel(const float* __restrict__ tap, int h, int w, int C,
+                                                                    float* __restrict__ feats, int C_total, int c_off,
+                                                                    int S, int f) {
+    __shared__ float tile[64][33];
+    const int tid = threadIdx.x;
+    const int xt = blockIdx.x, ys = blockIdx.y;
+    const int cchunks = (C + 63) / 64;
+    const int n = blockIdx.z / cchunks, c0 = (blockIdx.z - n * cchunks) * 64;
+    const int x0 = xt * 32;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * 256;                 // 512 float4 = 32 px x 16 channel quads
+        const int px = i >> 4, c4 = (i & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x0 + px < w && c0 + c4 < C) v = *(const float4*)(tap + (((size_t)n * h + ys) * w + x0 + px) * C + c0 + c4);
+        tile[c4 + 0][px] = v.x; tile[c4 + 1][px] = v.y; tile[c4 + 2][px] = v.z; tile[c4 + 3][px] = v.w;
+    }
+    __syncthreads();
+    const int row4 = 8 * f;                          // float4 per output row segment (32*f floats)
+    const int total = 64 * f * row4;                 // (channel, replicated row, float4)
+    for (int i = tid; i < total; i += 256) {
+        const int q = i % row4;
+        const int rr = i / row4;
+        const int fy = rr % f, c = rr / f;
+        if (c0 + c >= C) continue;
+        const int xo = q * 4;                        // output x offset inside the segment; f in {1,2,4,8}
+        float4 v;
+        v.x = tile[c][(xo + 0) / f]; v.y = tile[c][(xo + 1) / f]; v.z = tile[c][(xo + 2) / f]; v.w = tile[c][(xo + 3) / f];
+        const int ox = x0 * f + xo;
+        if (ox + 3 < S)
+            *(float4*)(feats + (((size_t)n * C_total + c_off + c0 + c) * S + ys * f + fy) * S + ox) = v;
+        else {
+            float* o = feats + (((size_t)n * C_total + c_off + c0 + c) * S + ys * f + fy) * S;
+            if (ox < S) o[ox] = v.x;
+            if (ox + 1 < S) o[ox + 1] = v.y;
+            if (ox + 2 < S) o[ox + 2] = v.z;
+        }
+    }
+}
+
 inline bool pixmap(int C, PixMap& m) {
     if (C % 4) return false;
     int v4 = C / 4, lpp = 1;
@@ -520,6 +563,12 @@ int op_colmax_finalize(const float* slab, int E, int C, int B, float* mx, hipStr
 
 int op_tap_to_features(const float* tap, int B, int h, int w, int C, float* feats, int C_total, int c_off, int S,
                        hipStream_t st) {
+    if (h == w && S % h == 0 && (S / h == 1 || S / h == 2 || S / h == 4 || S / h == 8) && C % 4 == 0 && S % 4 == 0 &&
+        (long long)B * ((C + 63) / 64) <= 65535) {
+        dim3 grid((w + 31) / 32, h, B * ((C + 63) / 64));
+        hipLaunchKernelGGL(tap_to_features_tiled_kernel, grid, dim3(256), 0, st, tap, h, w, C, feats, C_total, c_off, S, S / h);
+        return LAUNCH_OK();
+    }
     const long long total = (long long)B * C * S * S;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

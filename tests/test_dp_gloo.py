@@ -1,0 +1,58 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing bench.py uses for N > 1 (sharding, barrier,
+max-over-ranks timing, whole-job aggregation).  The GPU forward itself needs no collective."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from tedm_amd import dp
+    dist = dp.init('gloo')
+    assert dp.env_world() == (world, rank, rank)
+    beg, end = dp.shard_range(101, world, rank)
+    items = torch.arange(101)[beg:end]
+    import time
+
+    def step():
+        time.sleep(0.01 * (rank + 1))            # rank 1 is slower: the job time is the max over ranks
+        return float(items.sum())
+    elapsed, last = dp.timed_steps(step, steps=3, warmup=1, dist=dist)
+    total = dp.sum_over_ranks(dist, last)
+    n = dp.sum_over_ranks(dist, float(end - beg))
+    q.put((rank, beg, end, elapsed, total, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from tedm_amd import dp
+    for n in (0, 1, 7, 32, 101, 256):
+        for world in (1, 2, 3, 8):
+            r = [dp.shard_range(n, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_timing_and_aggregation():
+    world, port = 2, 29631
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, b0, e0, t0, tot0, n0), (r1, b1, e1, t1, tot1, n1) = res
+    assert (b0, e0, b1, e1) == (0, 51, 51, 101)
+    assert tot0 == tot1 == float(sum(range(101))) and n0 == n1 == 101.0
+    assert t0 == t1 and t0 >= 3 * 0.02 * 0.9                # both ranks report the slower rank's time
