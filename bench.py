@@ -83,8 +83,10 @@ def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):
     ddm = ddm.to(dev).eval()
     B, S = x0.shape[0], x0.shape[-1]
 
+    out = torch.empty(B, ddm.feature_channels * len(steps), S, S, dtype=torch.float32, device=dev)   # 40 GB at B=32
+
     def step():
-        return ddm.extract_features(x0, noise=noise)
+        return ddm.extract_features(x0, noise=noise, out=out)
     elapsed, feats = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
     if rank == 0:
         print(json.dumps({

@@ -43,15 +43,19 @@ class DatasetDM(nn.Module):
             nn.Conv2d(128, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
 
     @torch.no_grad()
-    def extract_features(self, x_0: Tensor, noise: Optional[Tensor] = None) -> Tensor:
-        """datasetDM_model.py:67-83.  Returns (B, feature_channels*T, S, S) fp32 on x_0's device."""
+    def extract_features(self, x_0: Tensor, noise: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+        """datasetDM_model.py:67-83.  Returns (B, feature_channels*T, S, S) fp32 on x_0's device
+        (written into `out` when given: the tensor is 40 GB at B=32, T=5, 256x256)."""
         if noise is not None:
             assert x_0.shape == noise.shape
         dm, unet = self.diffusion_model, self.diffusion_model.model
         B, _, H, W = x_0.shape
         assert H == W, 'extract_features resizes to [x.shape[-1]]*2 (datasetDM_model.py:81): square inputs only'
         S, T, dev = W, len(self.steps), x_0.device
-        feats = torch.empty(B, self.feature_channels * T, S, S, dtype=torch.float32, device=dev)
+        shape = (B, self.feature_channels * T, S, S)
+        if out is not None:
+            assert tuple(out.shape) == shape and out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
+        feats = out if out is not None else torch.empty(shape, dtype=torch.float32, device=dev)
         L = _lib.lib()
         per_call = max(1, self.max_images_per_forward // B) if B <= self.max_images_per_forward else 1
         for s0 in range(0, T, per_call):
