@@ -28,6 +28,13 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
                    float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream);
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
 
+/* Backward of one nn.Conv2d (same geometries as tedm_op_conv2d; `upsample` = the forward conv read the
+ * nearest-x2 upsampled x).  dy (B,Ho,Wo,Cout), x (B,H,W,Cin) NHWC; dx (B,H,W,Cin) and/or dw (Cout,Cin,k,k)
+ * OIHW may be NULL.  dgrad = the forward implicit-GEMM kernel with flipped/transposed packed weights (zero
+ * insertion for the stride-2 transpose, 2x2 sum-pool after the upsampled case); wgrad = wgrad.hip. */
+int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight_oihw, int B, int H, int W, int Cin,
+                            int Cout, int k, int stride, int upsample, float* dx, float* dw, int prec, void* stream);
+
 /* LinearAttention core (models/unet_model.py:197-207) through the fused sweeps of linattn_fused.hip:
  *   x (B,hw,C) fp32, PreNorm gain g (C), lnstats (B*hw,2) = (rstd, mean*rstd), wqkv_oihw (384,C,1,1);
  *   outputs: kmax (B,128) = max over pixels of k, ctx (B,4,32,32) = softmax_n(k) v^T / hw,

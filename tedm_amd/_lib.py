@@ -51,6 +51,8 @@ _SIGNATURES = {
                                   C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                   C.POINTER(C.c_int), C.c_int, _P]),
     'tedm_op_conv2d_stats_entries': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_op_conv2d_backward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           _P, _P, C.c_int, _P]),
     'tedm_op_linattn_fused': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_longlong, _P, _P, _P, C.c_int, _P]),
     'tedm_profile_enable': (C.c_int, [C.c_int]),
     'tedm_profile_reset': (C.c_int, []),

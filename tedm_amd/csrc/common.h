@@ -97,4 +97,6 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
 
 // ---- pack.hip -------------------------------------------------------------------------
 int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int fp16, hipStream_t st);
+int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int fp16,
+                            hipStream_t st);
 int copy_rows(const float* src, float* dst, long long n, hipStream_t st);

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     const int ct = cty * WN + wn;
     const bool active = ct < CT;                              // wave-uniform
     const int Cin = a.C1 + a.C2;
-    const int Hin = UPS ? a.H * 2 : a.H, Win = UPS ? a.W * 2 : a.W;
+    const int Hin = UPS ? a.H * 2 : a.H, Win = UPS ? a.W * 2 : a.W;   // UPS 1: nearest x2, UPS 2: zero insertion x2
 
     // ---- per-thread staging geometry of the tile being STAGED (same for all its channel chunks) ----
     int gp[G::NIT];        // >= 0: valid source pixel, -1 = zero padding, -2 = no piece
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
             if (pl < G::HR * G::HC) {
                 const int hy = pl / G::HC, hx = pl - hy * G::HC;
                 const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+                const bool valid = iy >= 0 && iy < Hin && ix >= 0 && ix < Win && (UPS != 2 || !((iy | ix) & 1));
                 const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
                 const int syc = sy < 0 ? 0 : (sy >= a.H ? a.H - 1 : sy), sxc = sx < 0 ? 0 : (sx >= a.W ? a.W - 1 : sx);
                 gpc[it] = (ns * a.H + syc) * a.W + sxc;
@@ -454,8 +454,10 @@ template <int PREC>
 int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st) {
     if (KH == 3 && stride == 1 && !ups && pro == PRO_NONE) return launch_tile<3, 3, 1, 1, 0, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
     if (KH == 3 && stride == 1 && !ups && pro == PRO_GN)   return launch_tile<3, 3, 1, 1, 0, 1, 2, PRO_GN, PREC>(a, tile_id, st);
-    if (KH == 3 && stride == 1 && ups && pro == PRO_NONE)  return launch_tile<3, 3, 1, 1, 1, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
+    if (KH == 3 && stride == 1 && ups == 1 && pro == PRO_NONE) return launch_tile<3, 3, 1, 1, 1, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
     if (KH == 4 && stride == 2 && !ups && pro == PRO_NONE) return launch_tile<4, 4, 2, 1, 0, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
+    // dgrad of the stride-2 Downsample: 4x4 stride-1 pad-2 conv over the zero-inserted gradient
+    if (KH == 4 && stride == 1 && ups == 2 && pro == PRO_NONE) return launch_tile<4, 4, 1, 2, 2, 1, 2, PRO_NONE, PREC>(a, tile_id, st);
     if (KH == 1 && stride == 1 && !ups) {
         if (pro == PRO_NONE) return launch_tile<1, 1, 1, 0, 0, 2, 1, PRO_NONE, PREC>(a, tile_id, st);
         if (pro == PRO_LN)   return launch_tile<1, 1, 1, 0, 0, 2, 1, PRO_LN, PREC>(a, tile_id, st);
@@ -477,7 +479,7 @@ int conv_set_tuning(const char* key, int v) {
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
     const int id = select_tile_id(a.Cout);
     const TileSel t = tile_geom(id, stride);
-    const int pad = KH == 1 ? 0 : 1, ks = KH == 1 ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
+    const int pad = KH == 1 ? 0 : (ups == 2 ? 2 : 1), ks = KH == 1 ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
              ks, nbuf, pro, a.prec);
 }

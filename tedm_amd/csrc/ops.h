@@ -40,4 +40,13 @@ int op_linattn_fused(int sweep /*0 kmax, 1 ctx, 2 q-out*/, const float* x, int C
                      const void* wpk, int B, long long hw, int heads, float* kmax_part, const float* kmax,
                      float* ctx_part, const float* ctx, float* o, int prec, hipStream_t st);
 
+// wgrad.hip
+size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo);
+int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho,
+                  int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
+                  float* dw, int accumulate, hipStream_t st);
+
+// backward.hip
+int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st);
+
 int conv_set_tuning(const char* key, int v);

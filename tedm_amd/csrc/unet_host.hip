@@ -749,6 +749,55 @@ int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* ln
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_linattn_fused failed (%d)", rc);
 }
 
+// ---- op-level entry point (tests): backward of one nn.Conv2d ----------------------------------------
+// dy (B,Ho,Wo,Cout) NHWC; x (B,H,W,Cin) NHWC = the tensor the forward conv read (before the optional
+// nearest x2 upsample); weight OIHW.  Outputs (either may be NULL): dx (B,H,W,Cin), dw (Cout,Cin,k,k).
+int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight_oihw, int B, int H, int W, int Cin,
+                            int Cout, int k, int stride, int upsample, float* dx, float* dw, int prec, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!dy || !weight_oihw || Cin % 16 || Cout % 16) return fail(TEDM_EINVAL, "bad argument");
+    int Ho, Wo;
+    if (k == 4 && stride == 2) { Ho = H / 2; Wo = W / 2; }
+    else if ((k == 3 || k == 1) && stride == 1) { Ho = upsample ? 2 * H : H; Wo = upsample ? 2 * W : W; }
+    else return fail(TEDM_EINVAL, "unsupported conv geometry");
+    int rc = TEDM_OK;
+    void* wpk = nullptr; float* tmp = nullptr; float* part = nullptr;
+    if (dx) {
+        const size_t bytes = conv_packed_bytes(Cin, Cout, k * k);
+        if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+        rc = pack_conv_weights_dgrad(weight_oihw, Cout, Cin, k, k, 0, Cin, wpk, prec == TEDM_PREC_FP16X2, st);
+        ConvArgs a{};
+        a.x1 = dy; a.C1 = Cout; a.B = B; a.H = Ho; a.W = Wo; a.Cout = Cin; a.wpk = wpk; a.prec = prec;
+        if (rc == TEDM_OK) {
+            if (k == 4) {                                  // transposed stride-2 conv: zero insertion + 4x4 pad 2
+                a.Ho = H; a.Wo = W; a.out = dx;
+                rc = conv_launch(a, 4, 1, 2, PRO_NONE, st);
+            } else if (upsample) {                         // dgrad at the upsampled resolution, then 2x2 sum-pool
+                if (hipMalloc((void**)&tmp, (size_t)B * Ho * Wo * Cin * 4) != hipSuccess) rc = TEDM_ENOMEM;
+                a.Ho = Ho; a.Wo = Wo; a.out = tmp;
+                if (rc == TEDM_OK) rc = conv_launch(a, 3, 1, 0, PRO_NONE, st);
+                if (rc == TEDM_OK) rc = op_pool2x2_sum(tmp, dx, B, H, W, Cin, st);
+            } else {
+                a.Ho = H; a.Wo = W; a.out = dx;
+                rc = conv_launch(a, k, 1, 0, PRO_NONE, st);
+            }
+        }
+    }
+    if (rc == TEDM_OK && dw) {
+        if (!x) rc = TEDM_EINVAL;
+        const size_t pf = wgrad_partial_floats(k, stride, Cout, Cin, B, Ho, Wo);
+        if (rc == TEDM_OK && hipMalloc((void**)&part, pf * 4) != hipSuccess) rc = TEDM_ENOMEM;
+        if (rc == TEDM_OK) rc = op_conv_wgrad(dy, Cout, x, Cin, nullptr, 0, B, H, W, Ho, Wo, k, stride, upsample, PRO_NONE,
+                                              nullptr, nullptr, part, dw, 0, st);
+    }
+    (void)hipStreamSynchronize(st);
+    if (wpk) (void)hipFree(wpk);
+    if (tmp) (void)hipFree(tmp);
+    if (part) (void)hipFree(part);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d_backward failed (%d)", rc);
+}
+
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo) { return conv_stats_entries(k, stride, Cout, Ho, Wo); }
 
 }  // extern "C"
