@@ -35,6 +35,19 @@ int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
 int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight_oihw, int B, int H, int W, int Cin,
                             int Cout, int k, int stride, int upsample, float* dx, float* dw, int prec, void* stream);
 
+/* Backward of Block's GroupNorm -> FiLM -> SiLU tail (models/unet_model.py:126-135) given the gradient G of the
+ * activated output and the raw conv output y (both (B,hw,C) NHWC).  fa, fb (B,C): the forward's folded
+ * coefficients (u = fa*y + fb); mr (B,groups,2) = (mean, rstd).  film: (1+scale) source, scale at
+ * [n*film_stride + c], shift at +C, or NULL; dfilm receives d scale / d shift in the same layout.
+ * Outputs: dy (B,hw,C) = gradient w.r.t. the conv output, dgamma, dbeta (C), dbias (C) = sum of dy. */
+int tedm_op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr,
+                             const float* gamma, const float* beta, const float* film, int film_stride, float* dfilm,
+                             int B, long long hw, int C, int groups, float* dy, float* dgamma, float* dbeta, float* dbias,
+                             void* stream);
+/* channel-LayerNorm backward (models/unet_model.py:52-61): dx = LN'(dY; x, g) [+ add], dg = sum_px dY * xhat. */
+int tedm_op_ln_backward(const float* dY, const float* x, const float* g, const float* add, long long P, int C, float* dx,
+                        float* dg, void* stream);
+
 /* LinearAttention core (models/unet_model.py:197-207) through the fused sweeps of linattn_fused.hip:
  *   x (B,hw,C) fp32, PreNorm gain g (C), lnstats (B*hw,2) = (rstd, mean*rstd), wqkv_oihw (384,C,1,1);
  *   outputs: kmax (B,128) = max over pixels of k, ctx (B,4,32,32) = softmax_n(k) v^T / hw,

@@ -27,7 +27,342 @@ __global__ void pool2x2_sum_kernel(const float* __restrict__ g, float* __restric
     }
 }
 
+TEDM_DEVFN float dsilu_f(float u) {            // d/du [u * sigmoid(u)]
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    return sg * (1.0f + u * (1.0f - sg));
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward of Block's tail: hact = silu(u), u = (xhat*gamma+beta)*(1+s)+t, xhat = (y-mean)*rstd
+// (models/unet_model.py:126-135).  u is re-evaluated from the raw conv output y with the folded
+// per-(n,c) coefficients of the forward (u = fa*y + fb).
+// Pass A: per (sample, pixel chunk, channel) partial sums  P0 = sum du,  P1 = sum du*xhat,  P2 = sum xhat,
+// with du = G * silu'(u).  Grid (E, B), one block per pixel chunk of one image.
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ y,
+                                                            const float* __restrict__ fa, const float* __restrict__ fb,
+                                                            const float* __restrict__ mr, int groups, long long hw, int C,
+                                                            int lpp, int ppb, float* __restrict__ slab /*[B][E][C][3]*/) {
+    __shared__ float red[4][3][64 * 4 * V];      // wave partials: [wave][comp][channel]
+    const int n = blockIdx.y, e = blockIdx.x, E = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const int cg = C / groups;
+    float4 a4[V], b4[V], mu[V], rs[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int c = (v * lpp + q) * 4;
+        a4[v] = *(const float4*)(fa + (size_t)n * C + c);
+        b4[v] = *(const float4*)(fb + (size_t)n * C + c);
+        const float* m0 = mr + ((size_t)n * groups) * 2;
+        mu[v] = make_float4(m0[((c + 0) / cg) * 2], m0[((c + 1) / cg) * 2], m0[((c + 2) / cg) * 2], m0[((c + 3) / cg) * 2]);
+        rs[v] = make_float4(m0[((c + 0) / cg) * 2 + 1], m0[((c + 1) / cg) * 2 + 1], m0[((c + 2) / cg) * 2 + 1], m0[((c + 3) / cg) * 2 + 1]);
+    }
+    float4 p0[V], p1[V], p2[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { p0[v] = p1[v] = p2[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    const long long pbeg = (long long)e * ppb, pend = (pbeg + ppb < hw) ? pbeg + ppb : hw;
+    for (long long p = pbeg + wave * ppw + sub; p < pend; p += 4 * ppw) {
+        const size_t base = ((size_t)n * hw + p) * C;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = (v * lpp + q) * 4;
+            const float4 g = *(const float4*)(G + base + c), yy = *(const float4*)(y + base + c);
+#define GN_ACC(F)                                                            \
+            { const float xh = (yy.F - mu[v].F) * rs[v].F;                   \
+              const float du = g.F * dsilu_f(fmaf(a4[v].F, yy.F, b4[v].F));  \
+              p0[v].F += du; p1[v].F = fmaf(du, xh, p1[v].F); p2[v].F += xh; }
+            GN_ACC(x) GN_ACC(y) GN_ACC(z) GN_ACC(w)
+#undef GN_ACC
+        }
+    }
+    // lanes with equal q hold the same channels: reduce over `sub`, then over the 4 waves through LDS
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+#define GN_RED(P, K)                                                                        \
+        { float4 t = P[v];                                                                  \
+          for (int m = lpp; m < 64; m <<= 1) { t.x += __shfl_xor(t.x, m); t.y += __shfl_xor(t.y, m); \
+                                               t.z += __shfl_xor(t.z, m); t.w += __shfl_xor(t.w, m); } \
+          if (sub == 0) *(float4*)&red[wave][K][(v * lpp + q) * 4] = t; }
+        GN_RED(p0, 0) GN_RED(p1, 1) GN_RED(p2, 2)
+#undef GN_RED
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 3; i += 256) {
+        const int k = i / C, c = i - k * C;
+        slab[(((size_t)n * E + e) * C + c) * 3 + k] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+    }
+}
+
+// Finalize per (sample, group): totals over the pixel chunks, then
+//   film grads  dshift[n,c] = P0,  dscale[n,c] = gamma*P1 + beta*P0          (Block FiLM, :130-132)
+//   per-sample contributions  dgam_n[n,c] = (1+s)*P1,  dbet_n[n,c] = (1+s)*P0,
+//   dbias_n[n,c] = sum_px dy = ca*P0 - hw*M0r - M1r*P2                        (conv bias grad)
+//   pass-B coefficients  ca[n,c] = rstd*gamma*(1+s),  M0r = rstd*mean_grp(dxhat),  M1r = rstd*mean_grp(dxhat*xhat)
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ slab, int E, int C, int groups,
+                                                             long long hw, const float* __restrict__ mr,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ film /*scale at [n*fs + c], or null*/,
+                                                             int film_stride, float* __restrict__ dfilm /*same layout, or null*/,
+                                                             float* __restrict__ ca, float* __restrict__ mcoef /*[B][groups][2]*/,
+                                                             float* __restrict__ dgam_n, float* __restrict__ dbet_n,
+                                                             float* __restrict__ dbias_n) {
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int cg = C / groups, lane = threadIdx.x;
+    const float rstd = mr[((size_t)n * groups + g) * 2 + 1];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = lane; i < cg; i += 64) {
+        const int c = g * cg + i;
+        double P0 = 0.0, P1 = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const float* sp = slab + (((size_t)n * E + e) * C + c) * 3;
+            P0 += sp[0]; P1 += sp[1];
+        }
+        const float sc = film ? film[(size_t)n * film_stride + c] + 1.f : 1.f;
+        s0 += (double)gamma[c] * sc * P0;
+        s1 += (double)gamma[c] * sc * P1;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+    const double cnt = (double)hw * cg;
+    const float M0r = (float)(s0 / cnt) * rstd, M1r = (float)(s1 / cnt) * rstd;
+    if (lane == 0) { mcoef[((size_t)n * groups + g) * 2] = M0r; mcoef[((size_t)n * groups + g) * 2 + 1] = M1r; }
+    for (int i = lane; i < cg; i += 64) {
+        const int c = g * cg + i;
+        double P0 = 0.0, P1 = 0.0, P2 = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const float* sp = slab + (((size_t)n * E + e) * C + c) * 3;
+            P0 += sp[0]; P1 += sp[1]; P2 += sp[2];
+        }
+        const float sc = film ? film[(size_t)n * film_stride + c] + 1.f : 1.f;
+        const float cac = rstd * gamma[c] * sc;
+        ca[(size_t)n * C + c] = cac;
+        dgam_n[(size_t)n * C + c] = (float)(sc * P1);
+        dbet_n[(size_t)n * C + c] = (float)(sc * P0);
+        dbias_n[(size_t)n * C + c] = (float)(cac * P0 - (double)hw * M0r - (double)M1r * P2);
+        if (dfilm) {
+            dfilm[(size_t)n * film_stride + c] = (float)(gamma[c] * P1 + beta[c] * P0);      // d scale
+            dfilm[(size_t)n * film_stride + C + c] = (float)P0;                             // d shift
+        }
+    }
+}
+
+// out[c] (+)= sum_n in[n][c]   (B <= a few hundred)
+__global__ void sum_over_batch_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int n = 0; n < B; ++n) s += in[(size_t)n * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// Pass B: dy = ca*du - M0r - xhat*M1r
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ y,
+                                                           const float* __restrict__ fa, const float* __restrict__ fb,
+                                                           const float* __restrict__ mr, const float* __restrict__ ca,
+                                                           const float* __restrict__ mcoef, int groups, long long hw, int C,
+                                                           int lpp, long long P, float* __restrict__ dy) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int cg = C / groups;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        if (p >= P) continue;
+        const int n = (int)(p / hw);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = (v * lpp + q) * 4;
+            const size_t o = (size_t)p * C + c;
+            const float4 g = *(const float4*)(G + o), yy = *(const float4*)(y + o);
+            const float4 a4 = *(const float4*)(fa + (size_t)n * C + c), b4 = *(const float4*)(fb + (size_t)n * C + c);
+            const float4 c4 = *(const float4*)(ca + (size_t)n * C + c);
+            float4 r;
+#define GN_APP(F, K)                                                                        \
+            { const int gi = (c + K) / cg;                                                  \
+              const float mu = mr[((size_t)n * groups + gi) * 2], rsd = mr[((size_t)n * groups + gi) * 2 + 1]; \
+              const float xh = (yy.F - mu) * rsd;                                           \
+              const float du = g.F * dsilu_f(fmaf(a4.F, yy.F, b4.F));                       \
+              r.F = c4.F * du - mcoef[((size_t)n * groups + gi) * 2] - xh * mcoef[((size_t)n * groups + gi) * 2 + 1]; }
+            GN_APP(x, 0) GN_APP(y, 1) GN_APP(z, 2) GN_APP(w, 3)
+#undef GN_APP
+            *(float4*)(dy + o) = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// channel-LayerNorm backward (models/unet_model.py:52-61; y = xhat * g, per pixel over channels):
+//   dx = rstd * (dxhat - mean_c(dxhat) - xhat * mean_c(dxhat*xhat)) [+ add],  dxhat = dY*g
+//   dg partial[c] = sum_px dY * xhat.   mean / rstd are re-derived from x (eps 1e-5), nothing is saved.
+template <int V>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ x,
+                                                     const float* __restrict__ g, const float* __restrict__ add,
+                                                     float* __restrict__ dx, float* __restrict__ dg_part /*[gridDim.x][C]*/,
+                                                     long long P, int C, int lpp) {
+    __shared__ float red[4][64 * 4 * V];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float4 gg[V], dgacc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { gg[v] = *(const float4*)(g + (v * lpp + q) * 4); dgacc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        float4 xv[V], dv[V];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const size_t o = (size_t)(ok ? p : 0) * C + (v * lpp + q) * 4;
+            xv[v] = *(const float4*)(x + o);
+            dv[v] = *(const float4*)(dY + o);
+            if (!ok) { xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); dv[v] = xv[v]; }
+            s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+        }
+        const float mean = group_sum(s, lpp) / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float a = xv[v].x - mean, b = xv[v].y - mean, c = xv[v].z - mean, d = xv[v].w - mean;
+            d2 += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rstd = rsqrtf(group_sum(d2, lpp) / (float)C + 1e-5f);
+        float m1 = 0.f, m2 = 0.f;
+        float4 xh[V], dh[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            xh[v] = make_float4((xv[v].x - mean) * rstd, (xv[v].y - mean) * rstd, (xv[v].z - mean) * rstd, (xv[v].w - mean) * rstd);
+            dh[v] = make_float4(dv[v].x * gg[v].x, dv[v].y * gg[v].y, dv[v].z * gg[v].z, dv[v].w * gg[v].w);
+            m1 += (dh[v].x + dh[v].y) + (dh[v].z + dh[v].w);
+            m2 += (dh[v].x * xh[v].x + dh[v].y * xh[v].y) + (dh[v].z * xh[v].z + dh[v].w * xh[v].w);
+            dgacc[v].x = fmaf(dv[v].x, xh[v].x, dgacc[v].x); dgacc[v].y = fmaf(dv[v].y, xh[v].y, dgacc[v].y);
+            dgacc[v].z = fmaf(dv[v].z, xh[v].z, dgacc[v].z); dgacc[v].w = fmaf(dv[v].w, xh[v].w, dgacc[v].w);
+        }
+        m1 = group_sum(m1, lpp) / (float)C;
+        m2 = group_sum(m2, lpp) / (float)C;
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const size_t o = (size_t)p * C + (v * lpp + q) * 4;
+                float4 r = make_float4(rstd * (dh[v].x - m1 - xh[v].x * m2), rstd * (dh[v].y - m1 - xh[v].y * m2),
+                                       rstd * (dh[v].z - m1 - xh[v].z * m2), rstd * (dh[v].w - m1 - xh[v].w * m2));
+                if (add) { const float4 ad = *(const float4*)(add + o); r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w; }
+                *(float4*)(dx + o) = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float4 t = dgacc[v];
+        for (int m = lpp; m < 64; m <<= 1) { t.x += __shfl_xor(t.x, m); t.y += __shfl_xor(t.y, m); t.z += __shfl_xor(t.z, m); t.w += __shfl_xor(t.w, m); }
+        if (sub == 0) *(float4*)&red[wave][(v * lpp + q) * 4] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        dg_part[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// per-channel sum over pixels: out_part[block][c] = sum of this block's pixels (bias grads of 1x1 convs etc.)
+template <int V>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, long long P, int C, int lpp) {
+    __shared__ float red[4][64 * 4 * V];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float4 acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long p = wave_id * ppw + sub; p < P; p += nwaves * ppw) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 t = *(const float4*)(x + (size_t)p * C + (v * lpp + q) * 4);
+            acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float4 t = acc[v];
+        for (int m = lpp; m < 64; m <<= 1) { t.x += __shfl_xor(t.x, m); t.y += __shfl_xor(t.y, m); t.z += __shfl_xor(t.z, m); t.w += __shfl_xor(t.w, m); }
+        if (sub == 0) *(float4*)&red[wave][(v * lpp + q) * 4] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        part[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+struct PixMap { int lpp, v; };
+inline bool pixmap(int C, PixMap& m) {
+    if (C % 4) return false;
+    int v4 = C / 4, lpp = 1;
+    while (lpp < 64 && (v4 % (lpp * 2)) == 0) lpp *= 2;
+    m.lpp = lpp; m.v = v4 / lpp;
+    return m.v >= 1 && m.v <= 4;
+}
+
 }  // namespace
+
+#define DISPATCH_V(mv, KERN, ...)                                                            \
+    switch (mv) {                                                                              \
+        case 1: hipLaunchKernelGGL(KERN<1>, __VA_ARGS__); break;                               \
+        case 2: hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); break;                               \
+        case 3: hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); break;                               \
+        default: hipLaunchKernelGGL(KERN<4>, __VA_ARGS__); break;                              \
+    }
+
+int gn_bwd_chunks(long long hw) { long long e = hw / 1024; return (int)(e < 1 ? 1 : e); }
+
+// GroupNorm(+FiLM)+SiLU backward.  Workspace (floats): slab B*E*C*3, ca B*C, mcoef B*groups*2, dgam_n/dbet_n/dbias_n B*C each.
+int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
+                        const float* beta, const float* film, int film_stride, float* dfilm, int B, long long hw, int C,
+                        int groups, float* slab, float* ca, float* mcoef, float* dgam_n, float* dbet_n, float* dbias_n,
+                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m) || C % groups) return TEDM_EINVAL;
+    const int E = gn_bwd_chunks(hw);
+    const int ppb = (int)((hw + E - 1) / E);
+    DISPATCH_V(m.v, gn_bwd_reduce_kernel, dim3(E, B), dim3(256), 0, st, G, y, fa, fb, mr, groups, hw, C, m.lpp, ppb, slab);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * groups), dim3(64), 0, st, slab, E, C, groups, hw, mr, gamma, beta, film,
+                       film_stride, dfilm, ca, mcoef, dgam_n, dbet_n, dbias_n);
+    const int cb = (C + 255) / 256;
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dgam_n, B, C, dgamma, accumulate);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dbet_n, B, C, dbeta, accumulate);
+    if (dbias) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dbias_n, B, C, dbias, accumulate);
+    const long long P = (long long)B * hw;
+    long long waves = (P + (64 / m.lpp) - 1) / (64 / m.lpp), blocks = (waves + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    DISPATCH_V(m.v, gn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, y, fa, fb, mr, ca, mcoef, groups, hw, C,
+               m.lpp, P, dy);
+    return LAUNCH_OK();
+}
+
+int ln_bwd_blocks(long long P, int C) {
+    PixMap m;
+    if (!pixmap(C, m)) return 0;
+    long long waves = (P + (64 / m.lpp) - 1) / (64 / m.lpp), blocks = (waves + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// dx = LN-backward(dY; x, g) [+ add]; dg (+)= sum_px dY*xhat.  part: ln_bwd_blocks(P,C)*C floats.
+int op_ln_backward(const float* dY, const float* x, const float* g, const float* add, float* dx, float* part, float* dg,
+                   int accumulate, long long P, int C, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    const int nb = ln_bwd_blocks(P, C);
+    DISPATCH_V(m.v, ln_bwd_kernel, dim3(nb), dim3(256), 0, st, dY, x, g, add, dx, part, P, C, m.lpp);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, dg, accumulate);
+    return LAUNCH_OK();
+}
+
+// out[c] (+)= sum over all P pixels of x[p][c].  part: ln_bwd_blocks(P,C)*C floats.
+int op_colsum(const float* x, float* part, float* out, int accumulate, long long P, int C, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    const int nb = ln_bwd_blocks(P, C);
+    DISPATCH_V(m.v, colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C, m.lpp);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, out, accumulate);
+    return LAUNCH_OK();
+}
 
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st) {
     if (C % 4) return TEDM_EINVAL;

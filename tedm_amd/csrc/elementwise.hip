@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           long long hw, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ film, int film_stride,
-                                                          float* __restrict__ oa, float* __restrict__ ob) {
+                                                          float* __restrict__ oa, float* __restrict__ ob,
+                                                          float* __restrict__ mr_out /*[B][groups][2] or null*/) {
     __shared__ double r1[256], r2[256];
     const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
     const int cg = C / groups;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float meanf = (float)mean;
+    if (mr_out && threadIdx.x == 0) { mr_out[(size_t)blockIdx.x * 2] = meanf; mr_out[(size_t)blockIdx.x * 2 + 1] = rstd; }
     for (int i = threadIdx.x; i < cg; i += 256) {
         const int c = g * cg + i;
         float a = rstd * gamma[c];
@@ -511,10 +513,11 @@ int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdi
 }
 
 int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
-                   const float* beta, const float* film, int film_stride, float* oa, float* ob, hipStream_t st) {
+                   const float* beta, const float* film, int film_stride, float* oa, float* ob, float* mr_out,
+                   hipStream_t st) {
     if (C % groups) return TEDM_EINVAL;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, st, slab, E, C, groups, hw, gamma, beta,
-                       film, film_stride, oa, ob);
+                       film, film_stride, oa, ob, mr_out);
     return LAUNCH_OK();
 }
 

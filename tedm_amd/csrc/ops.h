@@ -11,7 +11,8 @@ int op_time_embed(const float* t, const float* freqs, const float* w1, const flo
                   const float* b2, int B, int dim, int tdim, float* st_out, hipStream_t st);
 int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdim, int J, float* film, hipStream_t st);
 int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
-                   const float* beta, const float* film, int film_stride, float* oa, float* ob, hipStream_t st);
+                   const float* beta, const float* film, int film_stride, float* oa, float* ob, float* mr_out,
+                   hipStream_t st);
 int op_resblock_out(const float* y, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
                     int B, long long hw, int C, hipStream_t st);
 int op_ln_stats(const float* x, float* lnstats, long long P, int C, hipStream_t st);
@@ -48,5 +49,14 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
 
 // backward.hip
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st);
+int gn_bwd_chunks(long long hw);
+int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
+                        const float* beta, const float* film, int film_stride, float* dfilm, int B, long long hw, int C,
+                        int groups, float* slab, float* ca, float* mcoef, float* dgam_n, float* dbet_n, float* dbias_n,
+                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st);
+int ln_bwd_blocks(long long P, int C);
+int op_ln_backward(const float* dY, const float* x, const float* g, const float* add, float* dx, float* part, float* dg,
+                   int accumulate, long long P, int C, hipStream_t st);
+int op_colsum(const float* x, float* part, float* out, int accumulate, long long P, int C, hipStream_t st);
 
 int conv_set_tuning(const char* key, int v);

@@ -327,13 +327,13 @@ struct Fwd {
         CHECK(conv(r.c1, x1, C1, x2, C2, H, W, H, W, y1, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
         OP("gn_finalize", 0.0, 8.0 * B * E * C,
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block1.norm.weight"),
-                          u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr, u->film_J, ga, gb, st));
+                          u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr, u->film_J, ga, gb, nullptr, st));
         float* y2 = A->alloc((size_t)B * hw * C);
         CHECK(conv(r.c2, y1, C, nullptr, 0, H, W, H, W, y2, 1, 0, PRO_GN, ga, gb, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
         A->release(y1);
         OP("gn_finalize", 0.0, 8.0 * B * E * C,
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
-                          u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, st));
+                          u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, nullptr, st));
         float* o = A->alloc((size_t)B * hw * C);
         float* ln = lnstats ? A->alloc((size_t)B * hw * 2) : nullptr;
         if (r.has_res) {
@@ -796,6 +796,40 @@ int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight
     if (tmp) (void)hipFree(tmp);
     if (part) (void)hipFree(part);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d_backward failed (%d)", rc);
+}
+
+// ---- op-level entry points (tests): GroupNorm(+FiLM)+SiLU backward, channel-LayerNorm backward --------
+// G, y, dy: (B,hw,C) NHWC.  fa, fb: folded forward coefficients (u = fa*y + fb), mr: (B,groups,2) mean/rstd.
+// film: scale at [n*film_stride + c] (shift follows at +C) or NULL; dfilm same layout or NULL.
+int tedm_op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr,
+                             const float* gamma, const float* beta, const float* film, int film_stride, float* dfilm,
+                             int B, long long hw, int Cc, int groups, float* dy, float* dgamma, float* dbeta, float* dbias,
+                             void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int E = gn_bwd_chunks(hw);
+    float* ws = nullptr;
+    const size_t nf = (size_t)B * E * Cc * 3 + (size_t)B * Cc * 4 + (size_t)B * groups * 2;
+    if (hipMalloc((void**)&ws, nf * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    float* slab = ws; float* ca = slab + (size_t)B * E * Cc * 3; float* dg = ca + (size_t)B * Cc; float* db = dg + (size_t)B * Cc;
+    float* dbi = db + (size_t)B * Cc; float* mc = dbi + (size_t)B * Cc;
+    const int rc = op_gn_silu_backward(G, y, fa, fb, mr, gamma, beta, film, film_stride, dfilm, B, hw, Cc, groups, slab, ca, mc,
+                                       dg, db, dbi, dy, dgamma, dbeta, dbias, 0, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(ws);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_gn_silu_backward failed (%d)", rc);
+}
+
+int tedm_op_ln_backward(const float* dY, const float* x, const float* g, const float* add, long long P, int Cc, float* dx,
+                        float* dg, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = nullptr;
+    if (hipMalloc((void**)&part, (size_t)ln_bwd_blocks(P, Cc) * Cc * 4 + 16) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    const int rc = op_ln_backward(dY, x, g, add, dx, part, dg, 0, P, Cc, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(part);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_ln_backward failed (%d)", rc);
 }
 
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo) { return conv_stats_entries(k, stride, Cout, Ho, Wo); }

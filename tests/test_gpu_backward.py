@@ -70,3 +70,72 @@ def test_conv_backward(lib, dev, case):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # deterministic
     assert rel(outs[0][0], x.grad) < TOL
     assert rel(outs[0][1], w.grad) < TOL
+
+
+@pytest.mark.parametrize('B,H,W,Cc,film', [(2, 24, 40, 64, True), (3, 17, 9, 128, False), (2, 32, 64, 512, True)])
+def test_gn_film_silu_backward(lib, dev, B, H, W, Cc, film):
+    """Block tail (GroupNorm(8) -> x*(scale+1)+shift -> SiLU, unet_model.py:126-135) backward vs autograd."""
+    from tedm_amd import _lib
+    groups, hw = 8, H * W
+    y = rnd(B, Cc, H, W, seed=1).double().requires_grad_(True)
+    gamma = (1 + 0.2 * rnd(Cc, seed=2)).double().requires_grad_(True)
+    beta = (0.3 * rnd(Cc, seed=3)).double().requires_grad_(True)
+    ss = (0.3 * rnd(B, 2 * Cc, seed=4)).double().requires_grad_(True)
+    bias_probe = torch.zeros(Cc, dtype=torch.float64, requires_grad=True)        # d/d(conv bias) = sum of dy
+    yb = y + bias_probe[None, :, None, None]
+    z = F.group_norm(yb, groups, gamma, beta, eps=1e-5)
+    if film:
+        z = z * (ss[:, :Cc, None, None] + 1) + ss[:, Cc:, None, None]
+    out = F.silu(z)
+    G = rnd(*out.shape, seed=5).double()
+    out.backward(G)
+    # forward-side quantities the kernels consume
+    yg = y.detach().reshape(B, groups, -1)
+    mean, var = yg.mean(-1), yg.var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    mr = torch.stack((mean, rstd), -1)                                            # (B, groups, 2)
+    cg = Cc // groups
+    r_c, m_c = rstd.repeat_interleave(cg, 1), mean.repeat_interleave(cg, 1)       # (B, C)
+    sc = (ss.detach()[:, :Cc] + 1) if film else torch.ones(B, Cc, dtype=torch.float64)
+    sh = ss.detach()[:, Cc:] if film else torch.zeros(B, Cc, dtype=torch.float64)
+    fa = r_c * gamma.detach() * sc
+    fb = (beta.detach() - m_c * r_c * gamma.detach()) * sc + sh
+    d = lambda t: t.float().contiguous().to(dev)
+    Gd, yd = d(nhwc(G)), d(nhwc(y.detach()))
+    dy = torch.empty(B, H, W, Cc, device=dev)
+    dgam, dbet, dbias = (torch.empty(Cc, device=dev) for _ in range(3))
+    filmd = d(ss.detach()) if film else None
+    dfilm = torch.zeros(B, 2 * Cc, device=dev) if film else None
+    fad, fbd, mrd, gmd, btd = d(fa), d(fb), d(mr), d(gamma.detach()), d(beta.detach())     # keep the device tensors alive
+    _lib.check(lib.tedm_op_gn_silu_backward(Gd.data_ptr(), yd.data_ptr(), fad.data_ptr(), fbd.data_ptr(), mrd.data_ptr(),
+                                            gmd.data_ptr(), btd.data_ptr(),
+                                            filmd.data_ptr() if film else None, 2 * Cc, dfilm.data_ptr() if film else None,
+                                            B, hw, Cc, groups, dy.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), dbias.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream), 'gn bwd')
+    assert rel(dy.permute(0, 3, 1, 2), y.grad) < TOL
+    assert rel(dgam, gamma.grad) < TOL and rel(dbet, beta.grad) < TOL
+    assert rel(dbias, bias_probe.grad) < 1e-3 or float((dbias.cpu().double() - bias_probe.grad).abs().max()) < 1e-3
+    if film:
+        assert rel(dfilm, ss.grad) < TOL
+
+
+@pytest.mark.parametrize('P,Cc,with_add', [(1000, 64, True), (777, 512, False), (4096, 128, True)])
+def test_layernorm_backward(lib, dev, P, Cc, with_add):
+    from tedm_amd import _lib
+    x = rnd(P, Cc, seed=1).double().requires_grad_(True)
+    g = (1 + 0.1 * rnd(Cc, seed=2)).double().requires_grad_(True)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    out = (x - mean) * (var + 1e-5).rsqrt() * g
+    dY = rnd(P, Cc, seed=3).double()
+    out.backward(dY)
+    add = rnd(P, Cc, seed=4) if with_add else None
+    d = lambda t: t.float().contiguous().to(dev)
+    dx = torch.empty(P, Cc, device=dev)
+    dg = torch.empty(Cc, device=dev)
+    dYd, xd, gd, addd = d(dY), d(x.detach()), d(g.detach()), (d(add) if with_add else None)
+    _lib.check(lib.tedm_op_ln_backward(dYd.data_ptr(), xd.data_ptr(), gd.data_ptr(),
+                                       addd.data_ptr() if with_add else None, P, Cc, dx.data_ptr(), dg.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), 'ln bwd')
+    ref = x.grad + (add.double() if with_add else 0)
+    assert rel(dx, ref) < TOL
+    assert rel(dg, g.grad) < TOL
