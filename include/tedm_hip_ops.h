@@ -48,6 +48,12 @@ int tedm_op_gn_silu_backward(const float* G, const float* y, const float* fa, co
 int tedm_op_ln_backward(const float* dY, const float* x, const float* g, const float* add, long long P, int C, float* dx,
                         float* dg, void* stream);
 
+/* Attention cores on a materialised qkv tensor, forward + backward (tests of attention.hip / attention_bwd.hip):
+ * linear attention (unet_model.py:197-207): qkv (B,hw,384) -> o (B,hw,128); dout (B,hw,128) -> dqkv (B,hw,384);
+ * bottleneck attention (unet_model.py:229-239): qkv (B,ntok,384) -> o (B,ntok,128); dout -> dqkv. */
+int tedm_op_linattn_fwd_bwd(const float* qkv, const float* dout, int B, long long hw, float* o, float* dqkv, void* stream);
+int tedm_op_full_attention_fwd_bwd(const float* qkv, const float* dout, int B, int ntok, float* o, float* dqkv, void* stream);
+
 /* LinearAttention core (models/unet_model.py:197-207) through the fused sweeps of linattn_fused.hip:
  *   x (B,hw,C) fp32, PreNorm gain g (C), lnstats (B*hw,2) = (rstd, mean*rstd), wqkv_oihw (384,C,1,1);
  *   outputs: kmax (B,128) = max over pixels of k, ctx (B,4,32,32) = softmax_n(k) v^T / hw,

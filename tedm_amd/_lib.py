@@ -56,6 +56,8 @@ _SIGNATURES = {
     'tedm_op_gn_silu_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_longlong, C.c_int, C.c_int,
                                             _P, _P, _P, _P, _P]),
     'tedm_op_ln_backward': (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int, _P, _P, _P]),
+    'tedm_op_linattn_fwd_bwd': (C.c_int, [_P, _P, C.c_int, C.c_longlong, _P, _P, _P]),
+    'tedm_op_full_attention_fwd_bwd': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     'tedm_op_linattn_fused': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_longlong, _P, _P, _P, C.c_int, _P]),
     'tedm_profile_enable': (C.c_int, [C.c_int]),
     'tedm_profile_reset': (C.c_int, []),

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
 
 // pass 1 finalize: ctx[b][head][d][e] = sum_s ctx_p / (sum_s z_p[d] * hw)   (v / (h*w), :204)
 __global__ __launch_bounds__(256) void linattn_ctx_finalize_kernel(const float* __restrict__ part, int heads, int S,
-                                                                   long long hw, float* __restrict__ ctx) {
+                                                                   long long hw, float* __restrict__ ctx,
+                                                                   float* __restrict__ zout /*[B][heads][32] or null*/) {
     const int bh = blockIdx.x >> 2, b = bh / heads, head = bh - b * heads;      // 4 blocks per (sample, head)
     const int i = (blockIdx.x & 3) * 256 + threadIdx.x, d = i >> 5;
     float c = 0.f, z = 0.f;
@@ -77,13 +78,15 @@ __global__ __launch_bounds__(256) void linattn_ctx_finalize_kernel(const float* 
         z += cp[1024 + d];
     }
     ctx[(size_t)bh * 1024 + i] = c / (z * (float)hw);
+    if (zout && (i & 31) == 0) zout[(size_t)bh * 32 + d] = z;
 }
 
 // linear attention, pass 2: o[n][head*32+e] = sum_d ctx[d][e] * softmax_d(q[n][:])[d] * 32^-0.5
 // O^T[e][pixel] tile per wave: A = ctx^T (16 VGPRs, resident across pixel tiles), B = q' with one
 // pixel per lane so the softmax over d is lane-local plus one cross-half exchange.
 __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
-                                                          int B, long long hw, int heads, int tpw, float* __restrict__ o) {
+                                                          int B, long long hw, int heads, int tpw, float* __restrict__ o,
+                                                          float* __restrict__ qprime /*qkv base: store q' over q, or null*/) {
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const long long tiles = (hw + 31) / 32;
     const long long chunks = (tiles + tpw - 1) / tpw;
@@ -121,7 +124,13 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q[s] * f, acc, 0, 0, 0);
+        for (int s = 0; s < 16; ++s) { q[s] *= f; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q[s], acc, 0, 0, 0); }
+        if (ok && qprime) {                                   // training: keep q' = softmax_d(q)*scale for the backward
+            float* qw = qprime + ((size_t)b * hw + p) * C3 + head * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(qw + 4 * (2 * g + hh)) = make_float4(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
+        }
         if (ok) {
             float* op = o + ((size_t)b * hw + p) * CO + head * 32 + 4 * hh;
 #pragma unroll
@@ -137,7 +146,8 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 // One wave per (sample, head, 32-query tile); two sweeps over the key tiles (row max, then
 // exp / row sum / PV), S^T[key][query] kept in the accumulator so P feeds the PV MFMA directly.
 __global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ inv,
-                                                        int B, int ntok, int heads, float scale, float* __restrict__ o) {
+                                                        int B, int ntok, int heads, float scale, float* __restrict__ o,
+                                                        float* __restrict__ ml /*(B,ntok,heads,2) row max / row sum, or null*/) {
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int qtiles = (ntok + 31) / 32;
     const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict_
         }
     }
     l += __shfl_xor(l, 32);
+    if (qok && ml && hh == 0) { float* mp = ml + (((size_t)b * ntok + qi) * heads + head) * 2; mp[0] = m; mp[1] = l; }
     if (qok) {
         const float il = 1.f / l;
         float* op = o + ((size_t)b * ntok + qi) * CO + head * 32 + 4 * hh;
@@ -238,35 +249,37 @@ size_t la_ctx_partial_floats(int B, int heads, long long hw) {
 }
 
 int op_linattn_context(const float* qkv, const float* kmax, int B, long long hw, int heads, float* partial,
-                       float* ctx, hipStream_t st) {
+                       float* ctx, float* zout, hipStream_t st) {
     const int S = la_ctx_splits(hw);
     long long pps = (hw + S - 1) / S;
     pps += pps & 1;
     const long long waves = (long long)B * S * heads;
     hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, kmax, B, hw, heads,
                        S, pps, partial);
-    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx, zout);
     return LAUNCH_OK();
 }
 
 int op_linattn_ctx_finalize(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    float* zout = nullptr;
+    hipLaunchKernelGGL(linattn_ctx_finalize_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx, nullptr);
     return LAUNCH_OK();
 }
 
-int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, hipStream_t st) {
+int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, float* qprime_inplace,
+                   hipStream_t st) {
     const int tpw = 8;
     const long long tiles = (hw + 31) / 32, chunks = (tiles + tpw - 1) / tpw;
     const long long waves = (long long)B * chunks * heads;
     hipLaunchKernelGGL(linattn_out_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, ctx, B, hw, heads,
-                       tpw, o);
+                       tpw, o, qprime_inplace);
     return LAUNCH_OK();
 }
 
-int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o,
+int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o, float* ml,
                       hipStream_t st) {
     const long long waves = (long long)B * ((ntok + 31) / 32) * heads;
     hipLaunchKernelGGL(full_attn_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, qkv, inv_norm, B, ntok,
-                       heads, scale, o);
+                       heads, scale, o, ml);
     return LAUNCH_OK();
 }

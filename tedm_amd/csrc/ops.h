@@ -28,9 +28,10 @@ int op_tap_to_features(const float* tap, int B, int h, int w, int C, float* feat
 int la_ctx_splits(long long hw);
 size_t la_ctx_partial_floats(int B, int heads, long long hw);
 int op_linattn_context(const float* qkv, const float* kmax, int B, long long hw, int heads, float* partial,
-                       float* ctx, hipStream_t st);
-int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, hipStream_t st);
-int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o,
+                       float* ctx, float* zout, hipStream_t st);
+int op_linattn_out(const float* qkv, const float* ctx, int B, long long hw, int heads, float* o, float* qprime_inplace,
+                   hipStream_t st);
+int op_full_attention(const float* qkv, const float* inv_norm, int B, int ntok, int heads, float scale, float* o, float* ml,
                       hipStream_t st);
 
 int op_linattn_ctx_finalize(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st);
@@ -40,6 +41,13 @@ int la_fused_wgs_per_image(int sweep, long long hw);
 int op_linattn_fused(int sweep /*0 kmax, 1 ctx, 2 q-out*/, const float* x, int C, const float* g, const float* lnstats,
                      const void* wpk, int B, long long hw, int heads, float* kmax_part, const float* kmax,
                      float* ctx_part, const float* ctx, float* o, int prec, hipStream_t st);
+
+// attention_bwd.hip
+int op_linattn_backward(const float* qkv_qprime, const float* dout, const float* ctx, const float* kmax, const float* Z, int B,
+                        long long hw, int heads, float* part, float* dctx, float* T, float* dqkv, hipStream_t st);
+int op_full_attention_backward(const float* qkv, const float* inv, const float* out, const float* ml, const float* dout, int B,
+                               int ntok, int heads, float scale, float* delta, float* dqn, float* dkn, float* dv, float* dqkv,
+                               hipStream_t st);
 
 // wgrad.hip
 size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo);

@@ -385,10 +385,10 @@ struct Fwd {
             A->release(slab);
             float* part = A->alloc(la_ctx_partial_floats(B, heads, hw));
             float* ctx = A->alloc((size_t)B * heads * 1024);
-            OP("linattn_context", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, st));
+            OP("linattn_context", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_context(qkv, kmax, B, hw, heads, part, ctx, nullptr, st));
             A->release(part); A->release(kmax);
             o = A->alloc((size_t)P * u->hidden);
-            OP("linattn_out", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_out(qkv, ctx, B, hw, heads, o, st));
+            OP("linattn_out", 2048.0 * P * heads, 8.0 * P * u->hidden, op_linattn_out(qkv, ctx, B, hw, heads, o, nullptr, st));
             A->release(qkv); A->release(ctx);
         }
         float* z = A->alloc((size_t)P * C);
@@ -414,7 +414,7 @@ struct Fwd {
         OP("colnorm_finalize", 0.0, 8.0 * B * E * C3, op_colnorm_finalize(slab, E, C3, B, inv, st));
         A->release(slab);
         float* o = A->alloc((size_t)P * u->hidden);
-        OP("full_attention", 128.0 * B * heads * (double)hw * hw, 4.0 * P * (C3 + u->hidden), op_full_attention(qkv, inv, B, (int)hw, heads, 16.0f, o, st));
+        OP("full_attention", 128.0 * B * heads * (double)hw * hw, 4.0 * P * (C3 + u->hidden), op_full_attention(qkv, inv, B, (int)hw, heads, 16.0f, o, nullptr, st));
         A->release(qkv); A->release(inv);
         float* res = A->alloc((size_t)P * C);
         CHECK(conv(a.out, o, u->hidden, nullptr, 0, H, W, H, W, res, 1, 0, PRO_NONE, nullptr, nullptr, x, nullptr, nullptr, nullptr, STATS_NONE));
@@ -830,6 +830,58 @@ int tedm_op_ln_backward(const float* dY, const float* x, const float* g, const f
     (void)hipStreamSynchronize(st);
     (void)hipFree(part);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_ln_backward failed (%d)", rc);
+}
+
+// ---- op-level entry points (tests): attention forward (materialised qkv) + backward ------------------
+// Linear attention core on a given qkv (B,hw,384): forward to o (B,hw,128), then backward of `dout` to dqkv.
+int tedm_op_linattn_fwd_bwd(const float* qkv, const float* dout, int B, long long hw, float* o, float* dqkv, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int heads = 4, C3 = 384;
+    float* ws = nullptr;
+    const size_t n_part = la_ctx_partial_floats(B, heads, hw);
+    const size_t nf = (size_t)B * hw * C3 + (size_t)B * C3 * 2 + n_part + (size_t)B * heads * (1024 * 2 + 64);
+    if (hipMalloc((void**)&ws, nf * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    float* q2 = ws; float* kmax = q2 + (size_t)B * hw * C3; float* slabless = kmax + (size_t)B * C3;
+    float* part = slabless + (size_t)B * C3; float* ctx = part + n_part; float* dctx = ctx + (size_t)B * heads * 1024;
+    float* Z = dctx + (size_t)B * heads * 1024; float* T = Z + (size_t)B * heads * 32;
+    int rc = copy_rows(qkv, q2, (long long)B * hw * C3, st);
+    // kmax over pixels: treat qkv as a max slab with E = hw entries per sample
+    if (rc == TEDM_OK) rc = op_colmax_finalize(q2, (int)hw, C3, B, kmax, st);
+    if (rc == TEDM_OK) rc = op_linattn_context(q2, kmax, B, hw, heads, part, ctx, Z, st);
+    if (rc == TEDM_OK) rc = op_linattn_out(q2, ctx, B, hw, heads, o, q2, st);
+    if (rc == TEDM_OK) rc = op_linattn_backward(q2, dout, ctx, kmax, Z, B, hw, heads, part, dctx, T, dqkv, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(ws);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_linattn_fwd_bwd failed (%d)", rc);
+}
+
+// Bottleneck attention core on a given qkv (B,ntok,384): forward to o (B,ntok,128), backward of `dout` to dqkv.
+int tedm_op_full_attention_fwd_bwd(const float* qkv, const float* dout, int B, int ntok, float* o, float* dqkv, void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int heads = 4, C3 = 384, CO = 128;
+    float* ws = nullptr;
+    const size_t rows = (size_t)B * ntok;
+    const size_t nf = rows * C3 * 2 + (size_t)B * C3 + rows * heads * 3 + rows * CO * 3;
+    if (hipMalloc((void**)&ws, nf * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    float* slab = ws;                                     // (sum, sumsq) slab with E = ntok entries: [B][ntok][C3][2]
+    float* inv = slab + rows * C3 * 2; float* ml = inv + (size_t)B * C3; float* delta = ml + rows * heads * 2;
+    float* dqn = delta + rows * heads; float* dkn = dqn + rows * CO; float* dv = dkn + rows * CO;
+    // build the sumsq slab on the host side of the test helper: one entry per token
+    int rc = TEDM_OK;
+    {
+        std::vector<float> h(rows * C3), hs(rows * C3 * 2);
+        if (hipMemcpy(h.data(), qkv, rows * C3 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = TEDM_EHIP;
+        for (size_t i = 0; i < rows * C3; ++i) { hs[2 * i] = h[i]; hs[2 * i + 1] = h[i] * h[i]; }
+        if (rc == TEDM_OK && hipMemcpy(slab, hs.data(), rows * C3 * 8, hipMemcpyHostToDevice) != hipSuccess) rc = TEDM_EHIP;
+    }
+    if (rc == TEDM_OK) rc = op_colnorm_finalize(slab, ntok, C3, B, inv, st);
+    if (rc == TEDM_OK) rc = op_full_attention(qkv, inv, B, ntok, heads, 16.0f, o, ml, st);
+    if (rc == TEDM_OK) rc = op_full_attention_backward(qkv, inv, o, ml, dout, B, ntok, heads, 16.0f, delta, dqn, dkn, dv, dqkv, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(ws);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_full_attention_fwd_bwd failed (%d)", rc);
 }
 
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo) { return conv_stats_entries(k, stride, Cout, Ho, Wo); }

@@ -139,3 +139,46 @@ def test_layernorm_backward(lib, dev, P, Cc, with_add):
     ref = x.grad + (add.double() if with_add else 0)
     assert rel(dx, ref) < TOL
     assert rel(dg, g.grad) < TOL
+
+
+@pytest.mark.parametrize('B,hw', [(2, 1000), (3, 4096)])
+def test_linear_attention_core_backward(lib, dev, B, hw):
+    """unet_model.py:197-207 on a given qkv: o and d qkv vs autograd (fp64)."""
+    from tedm_amd import _lib
+    qkv = rnd(B, hw, 384, seed=1).double().requires_grad_(True)
+    hd = lambda t: t.reshape(B, hw, 4, 32).permute(0, 2, 3, 1)                    # b h d n
+    q, k, v = hd(qkv[..., :128]), hd(qkv[..., 128:256]), hd(qkv[..., 256:])
+    ctx = torch.einsum('bhdn,bhen->bhde', k.softmax(-1), v / hw)
+    o_ref = torch.einsum('bhde,bhdn->bhen', ctx, q.softmax(-2) * 32 ** -0.5).permute(0, 3, 1, 2).reshape(B, hw, 128)
+    dout = rnd(B, hw, 128, seed=2).double()
+    o_ref.backward(dout)
+    qd, dd = qkv.detach().float().to(dev), dout.float().to(dev)
+    o = torch.empty(B, hw, 128, device=dev)
+    dq = torch.empty(B, hw, 384, device=dev)
+    _lib.check(lib.tedm_op_linattn_fwd_bwd(qd.data_ptr(), dd.data_ptr(), B, hw, o.data_ptr(), dq.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream), 'linattn fwd/bwd')
+    assert rel(o, o_ref.detach()) < TOL
+    for nm, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
+        assert rel(dq[..., sl], qkv.grad[..., sl]) < 2e-4, nm
+
+
+@pytest.mark.parametrize('B,ntok', [(2, 64), (2, 1024), (1, 200)])
+def test_full_attention_core_backward(lib, dev, B, ntok):
+    """unet_model.py:229-239 on a given qkv (l2norm over tokens, scale 16): o and d qkv vs autograd (fp64)."""
+    from tedm_amd import _lib
+    qkv = rnd(B, ntok, 384, seed=5).double().requires_grad_(True)
+    hd = lambda t: t.reshape(B, ntok, 4, 32).permute(0, 2, 3, 1)                  # b h d n
+    q, k, v = hd(qkv[..., :128]), hd(qkv[..., 128:256]), hd(qkv[..., 256:])
+    q, k = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    attn = (torch.einsum('bhdi,bhdj->bhij', q, k) * 16).softmax(-1)
+    o_ref = torch.einsum('bhij,bhdj->bhid', attn, v).permute(0, 2, 1, 3).reshape(B, ntok, 128)
+    dout = rnd(B, ntok, 128, seed=6).double()
+    o_ref.backward(dout)
+    qd, dd = qkv.detach().float().to(dev), dout.float().to(dev)
+    o = torch.empty(B, ntok, 128, device=dev)
+    dq = torch.empty(B, ntok, 384, device=dev)
+    _lib.check(lib.tedm_op_full_attention_fwd_bwd(qd.data_ptr(), dd.data_ptr(), B, ntok, o.data_ptr(), dq.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), 'full attn fwd/bwd')
+    assert rel(o, o_ref.detach()) < TOL
+    for nm, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
+        assert rel(dq[..., sl], qkv.grad[..., sl]) < 2e-4, nm
