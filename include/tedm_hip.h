@@ -120,6 +120,35 @@ int tedm_q_sample(const float* x0, const float* noise, const int64_t* t,
 int tedm_tap_to_features(const float* tap, int B, int h, int w, int C,
                          float* feats, int C_total, int c_off, int S, void* stream);
 
+/* ---- training path -----------------------------------------------
+ * Replaces `loss.backward()` over Unet.forward in trainers/train_base_diffusion.py:36-47 (autograd through
+ * models/unet_model.py:333-368).  Protocol per optimizer step:
+ *   tedm_unet_pack + tedm_unet_pack_backward   (weights changed)       ->
+ *   tedm_unet_forward_train  (records a tape inside `workspace`)       ->
+ *   tedm_l1_loss             (loss value and d loss / d eps)           ->
+ *   tedm_unet_backward       (writes every bound gradient; no accumulation)
+ * Gradients use the reference parameter layouts (conv OIHW, Linear (out,in), vectors) so that a torch
+ * optimizer (or an RCCL all-reduce over a flat buffer) consumes them directly. */
+
+/* Bind the gradient buffer of one parameter (same keys / sizes as tedm_unet_set_param; every key except
+ * "time_mlp.0.freqs" must be bound before tedm_unet_backward). */
+int tedm_unet_set_grad(tedm_unet* h, const char* key, void* dev_ptr, long long numel);
+/* (Re)encode the data-gradient weight packs from the bound parameters. */
+int tedm_unet_pack_backward(tedm_unet* h, void* stream);
+/* Workspace bytes for one forward_train + backward at this shape (tape + backward scratch). */
+size_t tedm_unet_train_workspace_bytes(const tedm_unet* h, int B, int H, int W);
+/* Forward that keeps every tensor the backward reads in `workspace`.  flags: precision bits only. */
+int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B, int H, int W, float* eps_out,
+                            void* workspace, size_t workspace_bytes, void* stream, int flags);
+/* Backward of the recorded forward.  d_eps: (B, out_dim, H, W) fp32 = d loss / d eps.  Must be given the
+ * same workspace; consumes the tape (one backward per forward_train). */
+int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream);
+/* DiffusionModel.train_step's loss (models/diffusion_model.py:138-143):
+ *   loss = mean_b( mean_chw |eps - target| * p2w[t_b] ),  grad = d loss / d eps  (grad may be NULL).
+ * scratch: B*64 floats; loss: 1 float; all device pointers. */
+int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const float* p2w, int T, int B,
+                 long long chw, float* grad, float* scratch, float* loss, void* stream);
+
 const char* tedm_last_error(void);
 const char* tedm_version(void);
 

@@ -41,6 +41,12 @@ _SIGNATURES = {
     'tedm_unet_set_precision': (C.c_int, [_P, C.c_int]),
     'tedm_unet_workspace_bytes': (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     'tedm_unet_forward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P), _P, C.c_size_t, _P, C.c_int]),
+    'tedm_unet_set_grad': (C.c_int, [_P, C.c_char_p, _P, C.c_longlong]),
+    'tedm_unet_pack_backward': (C.c_int, [_P, _P]),
+    'tedm_unet_train_workspace_bytes': (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    'tedm_unet_forward_train': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
+    'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    'tedm_l1_loss': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, _P, _P, _P, _P]),
     'tedm_unet_trace_count': (C.c_int, [_P]),
     'tedm_unet_trace_name': (C.c_char_p, [_P, C.c_int]),
     'tedm_unet_trace_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

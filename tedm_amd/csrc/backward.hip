@@ -146,11 +146,13 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __rest
 }
 
 // out[c] (+)= sum_n in[n][c]   (B <= a few hundred)
-__global__ void sum_over_batch_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out, int accumulate) {
+__global__ void sum_over_batch_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out, int accumulate,
+                                      int stride = 0) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (stride == 0) stride = C;
     double s = 0.0;
-    for (int n = 0; n < B; ++n) s += in[(size_t)n * C + c];
+    for (int n = 0; n < B; ++n) s += in[(size_t)n * stride + c];
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -290,6 +292,198 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         part[(size_t)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// ---------------------------------------------------------------------------------------
+// small dense layers (time MLP, FiLM projections): y[b][j] = sum_k W[j][k] x[b][k] + bias[j]
+//   dW[j][k] (+)= sum_b dy[b][j] x[b][k];  db[j] (+)= sum_b dy[b][j];  dx[b][k] = sum_j dy[b][j] W[j][k]
+__global__ void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int J, int K,
+                                    int dy_stride, float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)J * K) return;
+    const int j = (int)(i / K), k = (int)(i - (long long)j * K);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = dy[(size_t)b * dy_stride + j]; s = fmaf(d, x[(size_t)b * K + k], s); sb += d; }
+    dW[i] = accumulate ? dW[i] + s : s;
+    if (k == 0 && db) db[j] = accumulate ? db[j] + sb : sb;
+}
+__global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int B, int J, int K,
+                                    int dy_stride, float* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i - b * K;
+    float s = 0.f;
+    for (int j = 0; j < J; ++j) s = fmaf(dy[(size_t)b * dy_stride + j], W[(size_t)j * K + k], s);
+    dx[i] = s;
+}
+// g *= act'(pre):  mode 0 SiLU (pre = input of the SiLU), mode 1 exact-erf GELU
+__global__ void act_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pre[i];
+    float d;
+    if (mode == 0) d = dsilu_f(x);
+    else d = 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    g[i] *= d;
+}
+
+// out = a + b
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+        ((float4*)out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// final_conv (1x1, C -> OD, NCHW output) backward: dX[p][c] = sum_o dY[n][o][pix] w[o][c];
+// dw partial[block][o][c] = sum_p dY*X, db partial[block][o] = sum_p dY.
+template <int V>
+__global__ __launch_bounds__(256) void final_conv_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ x,
+                                                             const float* __restrict__ w, float* __restrict__ dx,
+                                                             float* __restrict__ part /*[grid][OD][C+1]*/, long long P,
+                                                             long long hw, int C, int OD, int lpp) {
+    __shared__ float red[4][64 * 4 * V + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (int o = 0; o < OD; ++o) {
+        float4 acc[V]; float accb = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long p = wave_id * ppw + sub; p < P; p += nwaves * ppw) {
+            const long long n = p / hw, pix = p - n * hw;
+            const float d = dY[((size_t)n * OD + o) * hw + pix];
+            if (q == 0) accb += d;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const size_t off = (size_t)p * C + (v * lpp + q) * 4;
+                const float4 xx = *(const float4*)(x + off);
+                acc[v].x = fmaf(d, xx.x, acc[v].x); acc[v].y = fmaf(d, xx.y, acc[v].y);
+                acc[v].z = fmaf(d, xx.z, acc[v].z); acc[v].w = fmaf(d, xx.w, acc[v].w);
+                const float4 ww = *(const float4*)(w + (size_t)o * C + (v * lpp + q) * 4);
+                float4 r = make_float4(d * ww.x, d * ww.y, d * ww.z, d * ww.w);
+                if (o > 0) { const float4 pr = *(const float4*)(dx + off); r.x += pr.x; r.y += pr.y; r.z += pr.z; r.w += pr.w; }
+                *(float4*)(dx + off) = r;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float4 t = acc[v];
+            for (int m = lpp; m < 64; m <<= 1) { t.x += __shfl_xor(t.x, m); t.y += __shfl_xor(t.y, m); t.z += __shfl_xor(t.z, m); t.w += __shfl_xor(t.w, m); }
+            if (sub == 0) *(float4*)&red[wave][(v * lpp + q) * 4] = t;
+        }
+        for (int m = 1; m < 64; m <<= 1) accb += __shfl_xor(accb, m);
+        if (lane == 0) red[wave][64 * 4 * V] = accb;
+        __syncthreads();
+        for (int c = threadIdx.x; c <= C; c += 256) {
+            const int cc = c < C ? c : 64 * 4 * V;
+            part[((size_t)blockIdx.x * OD + o) * (C + 1) + c] = (red[0][cc] + red[1][cc]) + (red[2][cc] + red[3][cc]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stem (7x7, pad 3) weight gradient: dW[co][ci][ky][kx] = sum dY[n][y][x][co] * x[n][ci][y+ky-3][x+kx-3]
+// (NCHW input with few channels).  Each block walks `tpb` 8x32 tiles and writes one partial [Cin*49][Cout].
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ x, int B, int Cin,
+                                                         int H, int W, int Cout, int tpb, float* __restrict__ part) {
+    constexpr int TR = 8, TC = 32, HR = TR + 6, HC = TC + 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sdy = (float*)smem;                       // [256][64]
+    float* sx = sdy + 256 * 64;                      // [Cin][HR][HC]
+    const int tid = threadIdx.x, co_l = tid & 63, tq = tid >> 6;
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tpi = tiles_x * tiles_y, ntile = B * tpi;
+    const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntile) ? t_beg + tpb : ntile;
+    const int K = Cin * 49;
+    for (int cb = 0; cb < Cout; cb += 64) {
+        float acc[13];                                // taps tq, tq+4, ... of up to 49*Cin (Cin <= 1 per pass of 13*4=52 >= 49)
+        for (int kb = 0; kb < K; kb += 52) {
+#pragma unroll
+            for (int j = 0; j < 13; ++j) acc[j] = 0.f;
+            for (int tl = t_beg; tl < t_end; ++tl) {
+                const int n = tl / tpi, trem = tl - n * tpi, ty = trem / tiles_x, tx = trem - ty * tiles_x;
+                const int oy0 = ty * TR, ox0 = tx * TC;
+                __syncthreads();
+                for (int i = tid; i < 256 * 16; i += 256) {
+                    const int px = i >> 4, c4 = (i & 15) * 4;
+                    const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+                    const bool ok = oy < H && ox < W && cb + c4 < Cout;
+                    const int oyc = oy < H ? oy : H - 1, oxc = ox < W ? ox : W - 1, cc = cb + c4 < Cout ? cb + c4 : 0;
+                    float4 v = *(const float4*)(dY + ((size_t)(n * H + oyc) * W + oxc) * Cout + cc);
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)(sdy + px * 64 + c4) = v;
+                }
+                for (int i = tid; i < Cin * HR * HC; i += 256) {
+                    const int ci = i / (HR * HC), rem = i - ci * HR * HC, hy = rem / HC, hx = rem - hy * HC;
+                    const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+                    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                    const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];
+                    sx[i] = ok ? v : 0.f;
+                }
+                __syncthreads();
+                for (int px = 0; px < 256; ++px) {
+                    const float d = sdy[px * 64 + co_l];
+                    const int py = px >> 5, pxx = px & 31;
+#pragma unroll
+                    for (int j = 0; j < 13; ++j) {
+                        const int k = kb + tq + 4 * j;
+                        if (k < K) {
+                            const int ci = k / 49, tap = k - ci * 49, ky = tap / 7, kx = tap - ky * 7;
+                            acc[j] = fmaf(d, sx[(ci * HR + py + ky) * HC + pxx + kx], acc[j]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                const int k = kb + tq + 4 * j;
+                if (k < K && cb + co_l < Cout) part[((size_t)blockIdx.x * K + k) * Cout + cb + co_l] = acc[j];
+            }
+        }
+    }
+}
+// dW[co][k] (+)= sum_blocks part[block][k][co]
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nb, int K, int Cout, float* __restrict__ dW, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * Cout) return;
+    const int k = i / Cout, co = i - k * Cout;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[(size_t)b * K * Cout + i];
+    float* o = dW + (size_t)co * K + k;
+    *o = accumulate ? *o + s : s;
+}
+
+// ---------------------------------------------------------------------------------------
+// L1 epsilon loss with p2 weighting (models/diffusion_model.py:138-143) and its gradient:
+//   loss = mean_b( mean_chw |eps - target| * p2w[t_b] ),  grad = sign(eps - target) * p2w[t_b] / (B*chw)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ eps, const float* __restrict__ target,
+                                                      const long long* __restrict__ t, const float* __restrict__ p2w, int T, int B,
+                                                      long long chw, float* __restrict__ grad, float* __restrict__ part /*[B][gridDim.x]*/) {
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    long long ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
+    const float wgt = p2w[ti], gs = wgt / ((float)B * (float)chw);
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chw; i += (long long)gridDim.x * 256) {
+        const float d = eps[(size_t)b * chw + i] - target[(size_t)b * chw + i];
+        s += fabsf(d);
+        if (grad) grad[(size_t)b * chw + i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = red[0] * wgt;
+}
+__global__ void l1_loss_finalize_kernel(const float* __restrict__ part, int n, float denom, float* __restrict__ loss) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *loss = (float)(s / denom);
+    }
+}
+
 struct PixMap { int lpp, v; };
 inline bool pixmap(int C, PixMap& m) {
     if (C % 4) return false;
@@ -361,6 +555,73 @@ int op_colsum(const float* x, float* part, float* out, int accumulate, long long
     const int nb = ln_bwd_blocks(P, C);
     DISPATCH_V(m.v, colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C, m.lpp);
     hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, out, accumulate);
+    return LAUNCH_OK();
+}
+
+int op_linear_backward(const float* dy, int dy_stride, const float* x, const float* W, int B, int J, int K, float* dW, float* db,
+                       float* dx, int accumulate, hipStream_t st) {
+    if (dW) hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)(((long long)J * K + 255) / 256)), dim3(256), 0, st, dy, x, B, J, K,
+                               dy_stride, dW, db, accumulate);
+    if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, dy, W, B, J, K, dy_stride, dx);
+    return LAUNCH_OK();
+}
+int op_act_backward(float* g, const float* pre, int n, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, pre, n, mode);
+    return LAUNCH_OK();
+}
+int op_add2(const float* a, const float* b, float* out, long long n, hipStream_t st) {
+    if (n % 4) return TEDM_EINVAL;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, out, n / 4);
+    return LAUNCH_OK();
+}
+int final_conv_bwd_blocks(long long P) { long long b = P / 2048; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+// part: final_conv_bwd_blocks(P)*OD*(C+1) floats
+int op_final_conv_backward(const float* dY_nchw, const float* x, const float* w, float* dx, float* part, float* dw, float* db,
+                           int B, long long hw, int C, int OD, int accumulate, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m)) return TEDM_EINVAL;
+    const long long P = (long long)B * hw;
+    const int nb = final_conv_bwd_blocks(P);
+    DISPATCH_V(m.v, final_conv_bwd_kernel, dim3(nb), dim3(256), 0, st, dY_nchw, x, w, dx, part, P, hw, C, OD, m.lpp);
+    // part rows are [o][C+1]: treat as nb x (OD*(C+1)) and sum over blocks, then split into dw / db on the fly
+    for (int o = 0; o < OD; ++o) {
+        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part + (size_t)o * (C + 1), nb, C,
+                           dw + (size_t)o * C, accumulate, OD * (C + 1));
+        if (db) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(1), dim3(64), 0, st, part + (size_t)o * (C + 1) + C, nb, 1, db + o,
+                                   accumulate, OD * (C + 1));
+    }
+    return LAUNCH_OK();
+}
+int stem_wgrad_blocks(int B, int H, int W) {
+    const long long ntile = (long long)B * ((W + 31) / 32) * ((H + 7) / 8);
+    long long nb = ntile / 16;
+    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+// part: stem_wgrad_blocks*Cin*49*Cout floats
+int op_stem_wgrad(const float* dY, const float* x_nchw, int B, int Cin, int H, int W, int Cout, float* part, float* dW,
+                  int accumulate, hipStream_t st) {
+    const int nb = stem_wgrad_blocks(B, H, W);
+    const long long ntile = (long long)B * ((W + 31) / 32) * ((H + 7) / 8);
+    const int tpb = (int)((ntile + nb - 1) / nb);
+    const size_t lds = (size_t)(256 * 64 + Cin * 14 * 38) * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TEDM_EHIP;
+        attr = true;
+    }
+    const int nb2 = (int)((ntile + tpb - 1) / tpb);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb2), dim3(256), lds, st, dY, x_nchw, B, Cin, H, W, Cout, tpb, part);
+    const int K = Cin * 49;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((K * Cout + 255) / 256), dim3(256), 0, st, part, nb2, K, Cout, dW, accumulate);
+    return LAUNCH_OK();
+}
+// part: B*64 floats
+int op_l1_loss(const float* eps, const float* target, const long long* t, const float* p2w, int T, int B, long long chw,
+               float* grad, float* part, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(64, B), dim3(256), 0, st, eps, target, t, p2w, T, B, chw, grad, part);
+    hipLaunchKernelGGL(l1_loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, B * 64, (float)B * (float)chw, loss);
     return LAUNCH_OK();
 }
 

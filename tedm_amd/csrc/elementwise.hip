@@ -106,28 +106,37 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                   int dim, int tdim, float* __restrict__ st /*[B][tdim]*/) {
+                                                   int dim, int tdim, float* __restrict__ st /*[B][tdim]*/,
+                                                   float* __restrict__ save /*training tape or NULL*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* emb = (float*)smem;         // [dim]
     float* hid = emb + dim;            // [tdim]
-    const int b = blockIdx.x, half = dim / 2;
+    const int b = blockIdx.x, half = dim / 2, B = gridDim.x;
+    // tape sections: emb [B][dim] | pre-GELU [B][tdim] | post-GELU [B][tdim] | pre-SiLU [B][tdim]
+    float* s_emb = save ? save + (size_t)b * dim : nullptr;
+    float* s_t1 = save ? save + (size_t)B * dim + (size_t)b * tdim : nullptr;
+    float* s_hg = save ? s_t1 + (size_t)B * tdim : nullptr;
+    float* s_t2 = save ? s_hg + (size_t)B * tdim : nullptr;
     const float tv = t[b];
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         const float a = tv * freqs[i];
         emb[i] = sinf(a);
         emb[half + i] = cosf(a);
+        if (save) { s_emb[i] = emb[i]; s_emb[half + i] = emb[half + i]; }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
         float s = b1[j];
         for (int k = 0; k < dim; ++k) s = fmaf(w1[(size_t)j * dim + k], emb[k], s);
         hid[j] = 0.5f * s * (1.f + erff(s * 0.70710678118654752440f));
+        if (save) { s_t1[j] = s; s_hg[j] = hid[j]; }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
         float s = b2[j];
         for (int k = 0; k < tdim; ++k) s = fmaf(w2[(size_t)j * tdim + k], hid[k], s);
         st[(size_t)b * tdim + j] = silu_f(s);
+        if (save) s_t2[j] = s;
     }
 }
 
@@ -500,9 +509,9 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
 }
 
 int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
-                  const float* b2, int B, int dim, int tdim, float* st_out, hipStream_t st) {
+                  const float* b2, int B, int dim, int tdim, float* st_out, float* save, hipStream_t st) {
     hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(256), (size_t)(dim + tdim) * 4, st, t, freqs, w1, b1, w2, b2, dim,
-                       tdim, st_out);
+                       tdim, st_out, save);
     return LAUNCH_OK();
 }
 

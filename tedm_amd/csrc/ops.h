@@ -8,7 +8,7 @@ int op_q_sample(const float* x0, const float* noise, const long long* t, const f
 int op_stem_conv(const float* x_nchw, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                  int Cout, hipStream_t st);
 int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
-                  const float* b2, int B, int dim, int tdim, float* st_out, hipStream_t st);
+                  const float* b2, int B, int dim, int tdim, float* st_out, float* save /*tape or NULL*/, hipStream_t st);
 int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdim, int J, float* film, hipStream_t st);
 int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
                    const float* beta, const float* film, int film_stride, float* oa, float* ob, float* mr_out,
@@ -57,6 +57,18 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
 
 // backward.hip
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st);
+int op_linear_backward(const float* dy, int dy_stride, const float* x, const float* W, int B, int J, int K, float* dW, float* db,
+                       float* dx, int accumulate, hipStream_t st);
+int op_act_backward(float* g, const float* pre, int n, int mode /*0 silu, 1 gelu*/, hipStream_t st);
+int op_add2(const float* a, const float* b, float* out, long long n, hipStream_t st);
+int final_conv_bwd_blocks(long long P);
+int op_final_conv_backward(const float* dY_nchw, const float* x, const float* w, float* dx, float* part, float* dw, float* db,
+                           int B, long long hw, int C, int OD, int accumulate, hipStream_t st);
+int stem_wgrad_blocks(int B, int H, int W);
+int op_stem_wgrad(const float* dY, const float* x_nchw, int B, int Cin, int H, int W, int Cout, float* part, float* dW,
+                  int accumulate, hipStream_t st);
+int op_l1_loss(const float* eps, const float* target, const long long* t, const float* p2w, int T, int B, long long chw,
+               float* grad, float* part, float* loss, hipStream_t st);
 int gn_bwd_chunks(long long hw);
 int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
                         const float* beta, const float* film, int film_stride, float* dfilm, int B, long long hw, int C,

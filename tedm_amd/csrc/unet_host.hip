@@ -44,6 +44,10 @@ struct ConvW {           // one conv weight in packed MFMA-fragment form (handle
     bool has_bias = true;
     void* wpk = nullptr;
     size_t bytes = 0;
+    // training: data-gradient packs (flipped taps, Cin<->Cout swapped).  Convs over a virtual channel concat
+    // [x1 (split channels) | x2] carry one pack per input so that each dX is its own launch.
+    int split = 0;
+    void* wpk_d[2] = {nullptr, nullptr};
 };
 struct ResPlan { std::string pre; int cin = 0, cout = 0; bool has_res = false; int film_off = 0; ConvW c1, c2, res; };
 struct AttnPlan { std::string pre; int C = 0; bool linear = true; ConvW qkv, out; };
@@ -94,6 +98,22 @@ struct Arena {
 };
 
 struct Trace { std::string name; size_t off; int shape[4]; };
+
+// Training tape: every tensor of one forward that the backward reads (all inside the caller's workspace).
+struct ResTape { const float *x1 = nullptr, *x2 = nullptr; int C1 = 0, C2 = 0, H = 0, W = 0;
+                 float *y1 = nullptr, *y2 = nullptr, *fa1 = nullptr, *fb1 = nullptr, *mr1 = nullptr,
+                       *fa2 = nullptr, *fb2 = nullptr, *mr2 = nullptr, *out = nullptr; };
+struct AttnTape { const float* x = nullptr; int H = 0, W = 0;
+                  float *ln = nullptr, *qkv = nullptr, *kmax = nullptr, *Z = nullptr, *inv = nullptr, *ml = nullptr,
+                        *ctx = nullptr, *o = nullptr, *z = nullptr, *out = nullptr; };
+struct TailTape { const float* in = nullptr; float* out = nullptr; int H = 0, W = 0; };
+struct Tape {
+    int B = 0, H = 0, W = 0, prec = 0; bool film = false, valid = false;
+    const float* x_in = nullptr; float* r = nullptr; float* msave = nullptr; float* st = nullptr; float* filmbuf = nullptr;
+    std::vector<ResTape> d1, d2, u1, u2; std::vector<AttnTape> da, ua; std::vector<TailTape> dt, ut;
+    ResTape m1, m2, fin; AttnTape ma;
+    Arena arena;            // allocator state at the end of the forward; the backward continues from it
+};
 
 // HIP-event profiler: brackets kernel launches ON THE LAUNCH STREAM with event pairs and accumulates
 // per-kernel launches / time / algorithmic flops / algorithmic bytes.  level 1: convolutions only,
@@ -160,15 +180,22 @@ struct tedm_unet {
     bool packed = false;
     int prec = TEDM_PREC_BF16X3;       // arithmetic mode the packed weights are encoded for
     std::vector<Trace> trace;
+    std::vector<float*> grads;         // per-parameter gradient buffers (tedm_unet_set_grad), same order as params
+    bool packed_bwd = false;
+    Tape tape;
 
     ~tedm_unet() {
-        for (ConvW* c : convs) if (c->wpk) (void)hipFree(c->wpk);
+        for (ConvW* c : convs) {
+            if (c->wpk) (void)hipFree(c->wpk);
+            for (void* p : c->wpk_d) if (p) (void)hipFree(p);
+        }
         if (film_w) (void)hipFree(film_w);
         if (film_b) (void)hipFree(film_b);
     }
     void add_param(const std::string& key, long long numel) {
         index[key] = (int)params.size();
         params.push_back({key, numel, nullptr});
+        grads.push_back(nullptr);
     }
     const float* P(const std::string& key) const {
         auto it = index.find(key);
@@ -180,8 +207,9 @@ struct tedm_unet {
         if (bias) add_param(pre + ".bias", cout);
         convs.push_back(&c);
     }
-    void add_res(ResPlan& r, const std::string& pre, int cin, int cout) {
+    void add_res(ResPlan& r, const std::string& pre, int cin, int cout, int split = 0) {
         r.pre = pre; r.cin = cin; r.cout = cout; r.has_res = cin != cout;
+        r.c1.split = split; r.res.split = split;
         r.film_off = film_J; film_J += 2 * cout;
         add_param(pre + ".time_mlp.1.weight", (long long)2 * cout * tdim);
         add_param(pre + ".time_mlp.1.bias", 2 * cout);
@@ -258,13 +286,13 @@ int build_plan(tedm_unet* u) {
         const bool last = i == u->nres - 1;
         const std::string pre = "ups." + std::to_string(i);
         LevelPlan& L = u->ups[i];
-        u->add_res(L.b1, pre + ".0", dout + din, dout);
-        u->add_res(L.b2, pre + ".1", dout + din, dout);
+        u->add_res(L.b1, pre + ".0", dout + din, dout, dout);
+        u->add_res(L.b2, pre + ".1", dout + din, dout, dout);
         u->add_attn(L.attn, pre + ".2", dout, true);
         L.tail_kind = last ? 1 : 2;
         u->add_conv(L.tail, last ? pre + ".3" : pre + ".3.1", din, dout, 3, true);
     }
-    u->add_res(u->fin, "final_res_block", c.dim * 2, c.dim);
+    u->add_res(u->fin, "final_res_block", c.dim * 2, c.dim, c.dim);
     if (u->init_dim != c.dim) return fail(TEDM_EINVAL, "init_dim != dim is not supported (final_res_block expects 2*dim inputs)");
     u->add_param("final_conv.weight", (long long)u->out_dim * c.dim);
     u->add_param("final_conv.bias", u->out_dim);
@@ -438,7 +466,7 @@ struct Fwd {
             filmbuf = A->alloc((size_t)B * u->film_J);
             OP("time_embed", 2.0 * B * u->tdim * (dim + u->tdim), 4.0 * u->tdim * (dim + u->tdim),
                op_time_embed(t, u->P("time_mlp.0.freqs"), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
-                             u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, st));
+                             u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, nullptr, st));
             OP("film_proj", 2.0 * B * u->tdim * u->film_J, 4.0 * u->tdim * u->film_J,
                op_film(stb, u->film_w, u->film_b, B, u->tdim, u->film_J, filmbuf, st));
             A->release(stb);
@@ -530,6 +558,8 @@ int check_shape(const tedm_unet* u, int B, int H, int W) {
     return TEDM_OK;
 }
 
+#include "unet_train.inc"
+
 }  // namespace
 
 extern "C" {
@@ -566,7 +596,7 @@ int tedm_unet_set_param(tedm_unet* h, const char* key, const void* dev_ptr, long
     if (it == h->index.end()) return fail(TEDM_ENOKEY, "unknown parameter key '%s'", key);
     Param& p = h->params[it->second];
     if (p.numel != numel) return fail(TEDM_EINVAL, "parameter '%s': expected %lld elements, got %lld", key, p.numel, numel);
-    if (p.ptr != dev_ptr) h->packed = false;
+    if (p.ptr != dev_ptr) { h->packed = false; h->packed_bwd = false; }
     p.ptr = (const float*)dev_ptr;
     return TEDM_OK;
 }
@@ -599,7 +629,7 @@ int tedm_unet_set_precision(tedm_unet* h, int prec) {
     g_err[0] = 0;
     if (!h) return fail(TEDM_EINVAL, "null handle");
     if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
-    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) h->packed = false;
+    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) { h->packed = false; h->packed_bwd = false; }
     h->prec = prec;
     return TEDM_OK;
 }
@@ -643,6 +673,111 @@ int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H
     if (A.oom) return fail(TEDM_ENOMEM, "workspace overflow");
     if (hipGetLastError() != hipSuccess) return fail(TEDM_EHIP, "HIP launch error");
     return TEDM_OK;
+}
+
+// ---- training path ------------------------------------------------------------------------------------
+int tedm_unet_set_grad(tedm_unet* h, const char* key, void* dev_ptr, long long numel) {
+    g_err[0] = 0;
+    if (!h || !key) return fail(TEDM_EINVAL, "null argument");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(TEDM_ENOKEY, "unknown parameter key '%s'", key);
+    if (dev_ptr && h->params[it->second].numel != numel)
+        return fail(TEDM_EINVAL, "gradient '%s': expected %lld elements, got %lld", key, h->params[it->second].numel, numel);
+    h->grads[it->second] = (float*)dev_ptr;
+    return TEDM_OK;
+}
+
+int tedm_unet_pack_backward(tedm_unet* h, void* stream) {
+    g_err[0] = 0;
+    if (!h) return fail(TEDM_EINVAL, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    const int fp16 = h->prec == TEDM_PREC_FP16X2;
+    for (ConvW* c : h->convs) {
+        const float* w = h->P(c->key + ".weight");
+        if (!w) return fail(TEDM_ESTATE, "parameter '%s.weight' is not bound", c->key.c_str());
+        const int n0 = c->split ? c->split : c->cin, n1 = c->split ? c->cin - c->split : 0;
+        if (!c->wpk_d[0] && hipMalloc(&c->wpk_d[0], conv_packed_bytes(n0, c->cout, c->k * c->k)) != hipSuccess)
+            return fail(TEDM_ENOMEM, "hipMalloc for the dgrad pack of %s failed", c->key.c_str());
+        if (n1 && !c->wpk_d[1] && hipMalloc(&c->wpk_d[1], conv_packed_bytes(n1, c->cout, c->k * c->k)) != hipSuccess)
+            return fail(TEDM_ENOMEM, "hipMalloc for the dgrad pack of %s failed", c->key.c_str());
+        CHECK(pack_conv_weights_dgrad(w, c->cout, c->cin, c->k, c->k, 0, n0, c->wpk_d[0], fp16, st));
+        if (n1) CHECK(pack_conv_weights_dgrad(w, c->cout, c->cin, c->k, c->k, n0, n1, c->wpk_d[1], fp16, st));
+    }
+    h->packed_bwd = true;
+    return TEDM_OK;
+}
+
+size_t tedm_unet_train_workspace_bytes(const tedm_unet* h, int B, int H, int W) {
+    g_err[0] = 0;
+    if (!h || check_shape(h, B, H, W) != TEDM_OK) return 0;
+    Arena A;
+    A.dry = true;
+    Tape tape;
+    tedm_unet* u = const_cast<tedm_unet*>(h);
+    Train tr{u, &A, nullptr, true, B, 0, &tape, Fwd{u, &A, nullptr, true, B, 0, true, nullptr, false}};
+    static const float dummy_t = 0.f;
+    if (tr.forward(nullptr, &dummy_t, H, W, nullptr) != TEDM_OK) return 0;
+    if (tr.backward(nullptr) != TEDM_OK) return 0;
+    return A.peak + 256;
+}
+
+int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B, int H, int W, float* eps_out,
+                            void* workspace, size_t workspace_bytes, void* stream, int flags) {
+    g_err[0] = 0;
+    if (!h || !x || !workspace || !eps_out) return fail(TEDM_EINVAL, "null argument");
+    if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
+    CHECK(check_shape(h, B, H, W));
+    const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
+    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2))
+        return fail(TEDM_ESTATE, "weights are packed for precision mode %d, forward asks for %d", h->prec, prec);
+    const size_t need = tedm_unet_train_workspace_bytes(h, B, H, W);
+    if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
+    if (workspace_bytes < need) return fail(TEDM_ENOMEM, "training workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Arena A;
+    const size_t mis = (size_t)((uintptr_t)workspace & 255);
+    A.base = (char*)workspace + (mis ? 256 - mis : 0);
+    A.cap = workspace_bytes - (mis ? 256 - mis : 0);
+    A.dry = false;
+    h->tape = Tape();
+    hipStream_t st = (hipStream_t)stream;
+    Train tr{h, &A, st, false, B, prec, &h->tape, Fwd{h, &A, st, false, B, prec, t != nullptr, nullptr, false}};
+    const int rc = tr.forward(x, t, H, W, eps_out);
+    if (rc != TEDM_OK) { h->tape.valid = false; return rc; }
+    if (A.oom) { h->tape.valid = false; return fail(TEDM_ENOMEM, "workspace overflow"); }
+    if (hipGetLastError() != hipSuccess) { h->tape.valid = false; return fail(TEDM_EHIP, "HIP launch error"); }
+    h->tape.arena = A;
+    return TEDM_OK;
+}
+
+int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    if (!h || !d_eps || !workspace) return fail(TEDM_EINVAL, "null argument");
+    Tape& T = h->tape;
+    if (!T.valid) return fail(TEDM_ESTATE, "no training tape: call tedm_unet_forward_train first");
+    if (!h->packed_bwd) return fail(TEDM_ESTATE, "tedm_unet_pack_backward() has not been called since parameters were (re)bound");
+    const size_t mis = (size_t)((uintptr_t)workspace & 255);
+    if ((char*)workspace + (mis ? 256 - mis : 0) != T.arena.base || workspace_bytes - (mis ? 256 - mis : 0) != T.arena.cap)
+        return fail(TEDM_ESTATE, "backward must be given the workspace of the recorded forward");
+    Arena A = T.arena;
+    hipStream_t st = (hipStream_t)stream;
+    Train tr{h, &A, st, false, T.B, T.prec, &T, Fwd{h, &A, st, false, T.B, T.prec, T.film, T.filmbuf, false}};
+    const int rc = tr.backward(d_eps);
+    T.valid = false;                                        // the backward reuses tape storage (q' etc. stay, scratch does not)
+    if (rc != TEDM_OK) return rc;
+    if (A.oom) return fail(TEDM_ENOMEM, "workspace overflow");
+    if (hipGetLastError() != hipSuccess) return fail(TEDM_EHIP, "HIP launch error");
+    return TEDM_OK;
+}
+
+// L1 epsilon loss with p2 weighting (models/diffusion_model.py:138-143) and d loss / d eps.
+// scratch: B*64 floats.  loss: one float (device).
+int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const float* p2w, int T, int B, long long chw,
+                 float* grad, float* scratch, float* loss, void* stream) {
+    g_err[0] = 0;
+    if (!eps || !target || !t || !p2w || !scratch || !loss) return fail(TEDM_EINVAL, "null argument");
+    const int rc = op_l1_loss(eps, target, (const long long*)t, p2w, T, B, chw, grad, scratch, loss, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "l1 loss launch failed");
 }
 
 int tedm_unet_trace_count(const tedm_unet* h) { return h ? (int)h->trace.size() : 0; }

@@ -111,6 +111,47 @@ class DiffusionModel(nn.Module):
         loss = (out - target).abs().flatten(1).mean(dim=1)
         return (loss * self.p2_loss_weight.gather(-1, t)).mean()
 
+    def l1_loss_native(self, eps: Tensor, target: Tensor, t: Tensor, want_grad: bool = False):
+        """diffusion_model.py:138-143 as one HIP kernel: returns (loss, d loss / d eps or None)."""
+        dev = eps.device
+        B = eps.shape[0]
+        e, tg = eps.detach().float().contiguous(), target.detach().float().contiguous()
+        tt = t.detach().to(device=dev, dtype=torch.int64).contiguous()
+        grad = torch.empty_like(e) if want_grad else None
+        scratch = torch.empty(B * 64, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tedm_l1_loss(
+                e.data_ptr(), tg.data_ptr(), tt.data_ptr(), self.p2_loss_weight.data_ptr(), self.timesteps, B,
+                e[0].numel(), grad.data_ptr() if want_grad else None, scratch.data_ptr(), loss.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream), 'tedm_l1_loss')
+        return loss, grad
+
+    def train_step_native(self, x_0: Tensor, cond: Optional[Tensor] = None, t: Optional[Tensor] = None,
+                          noise: Optional[Tensor] = None) -> Tensor:
+        """`train_step` + `loss.backward()` (trainers/train_base_diffusion.py:36-47) without autograd:
+        q-sample, recorded UNet forward, L1/p2 loss and the whole backward as HIP kernels.  Every
+        `param.grad` of the UNet is (re)pointed at its view of `model.grad_flat` and OVERWRITTEN, which is
+        what a zero_grad() + backward() pair leaves behind; a data-parallel trainer all-reduces
+        `model.grad_flat` once.  Returns the detached loss."""
+        N, dev = x_0.shape[0], x_0.device
+        t = t.long().to(dev) if t is not None else torch.randint(0, self.timesteps, (N,), device=dev).long()
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        if self.objective == 'pred_noise':
+            target = noise
+        elif self.objective == 'pred_x_0':
+            target = x_0
+        else:
+            raise ValueError(f'unknown objective {self.objective}')
+        x_t = self._q_sample(x_0, t, noise, normalize=bool(self.config.normalize))
+        eps = self.model.native_forward_train(x_t, t)
+        loss, grad = self.l1_loss_native(eps, target, t, want_grad=True)
+        views = self.model.native_backward(grad)
+        for k, p in self.model.named_parameters():
+            p.grad = views[k]
+        return loss
+
     def val_step(self, x_0: Tensor, cond: Optional[Tensor] = None, t_steps: Optional[int] = None) -> Tensor:
         """diffusion_model.py:145-156."""
         t_steps = t_steps or self.timesteps

@@ -137,6 +137,23 @@ def Downsample(dim: int, dim_out: Optional[int] = None) -> nn.Conv2d:
     return nn.Conv2d(dim, dim_out or dim, 4, 2, 1)
 
 
+class _UnetTrainFn(torch.autograd.Function):
+    """autograd bridge: forward = tedm_unet_forward_train, backward = tedm_unet_backward.  Gradients are
+    returned as copies of the `grad_flat` views so that autograd's accumulation semantics hold."""
+
+    @staticmethod
+    def forward(ctx, unet, x, timestep, names, *params):
+        ctx.unet, ctx.names = unet, names
+        ctx.mask = [p.requires_grad for p in params]
+        return unet.native_forward_train(x, timestep)
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        views = ctx.unet.native_backward(d_eps)
+        grads = [views[k].clone() if m else None for k, m in zip(ctx.names, ctx.mask)]
+        return (None, None, None, None, *grads)
+
+
 class Unet(nn.Module):
     def __init__(self, dim: int = 64, init_dim: Optional[int] = None, out_dim: Optional[int] = None,
                  dim_mults: Sequence[int] = (1, 2, 4, 8), channels: int = 1, resnet_block_groups: int = 8,
@@ -189,6 +206,11 @@ class Unet(nn.Module):
         self._fingerprint = None
         self._bound: List[Tensor] = []          # keeps converted parameter copies alive
         self._workspace: Optional[Tensor] = None
+        self._train_ws: Optional[Tensor] = None
+        self._bwd_fingerprint = None
+        self.grad_flat: Optional[Tensor] = None     # one flat fp32 buffer holding every parameter gradient
+        self._grad_views: Dict[str, Tensor] = {}
+        self._grad_handle = None
         self.precision = os.environ.get('TEDM_PREC', 'bf16x3')   # 'bf16x3' (parity mode) | 'bf16'
         self.last_trace: Dict[str, Tensor] = {}
 
@@ -282,9 +304,9 @@ class Unet(nn.Module):
                                '(use oracle/ for a CPU restatement in tests)')
         if x.dim() != 4 or x.shape[1] != self.channels:
             raise ValueError(f'expected input (B,{self.channels},H,W), got {tuple(x.shape)}')
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError('tedm_amd.Unet: backward kernels are not implemented yet; '
-                                      'call under torch.no_grad()')
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError('tedm_amd.Unet: gradients w.r.t. the input image are not computed '
+                                      '(the reference never asks for them); detach x')
         L = _lib.lib()
         dev = x.device
         B, _, H, W = x.shape
@@ -321,6 +343,73 @@ class Unet(nn.Module):
                 taps = [t.permute(0, 3, 1, 2) for t in taps]     # NCHW-shaped views of the NHWC buffers
         return eps, taps
 
+    # -- training path ------------------------------------------------------------------------
+    def grad_views(self, device: torch.device) -> Dict[str, Tensor]:
+        """Per-parameter views into `grad_flat` (allocated and bound to the native handle on first use)."""
+        L = _lib.lib()
+        self._ensure_handle(device)
+        params = dict(self.named_parameters())
+        if self.grad_flat is None or self.grad_flat.device != device:
+            total = sum(p.numel() for p in params.values())
+            self.grad_flat = torch.zeros(total, dtype=torch.float32, device=device)
+            self._grad_views, off = {}, 0
+            for k, p in params.items():
+                self._grad_views[k] = self.grad_flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._grad_handle = None
+        if self._grad_handle is not self._handle:
+            for k, v in self._grad_views.items():
+                _lib.check(L.tedm_unet_set_grad(self._handle, k.encode(), v.data_ptr(), v.numel()), f'set_grad({k})')
+            self._grad_handle = self._handle
+        return self._grad_views
+
+    def native_forward_train(self, x: Tensor, timestep: Optional[Tensor]) -> Tensor:
+        """HIP forward that records the tape for `native_backward` in the training workspace."""
+        if not x.is_cuda:
+            raise RuntimeError('tedm_amd.Unet runs on a ROCm GPU only: there is no CPU fallback')
+        if x.dim() != 4 or x.shape[1] != self.channels:
+            raise ValueError(f'expected input (B,{self.channels},H,W), got {tuple(x.shape)}')
+        L = _lib.lib()
+        dev = x.device
+        B, _, H, W = x.shape
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._ensure_handle(dev)
+            self._sync_params(dev, stream)
+            if self._bwd_fingerprint != self._fingerprint:
+                _lib.check(L.tedm_unet_pack_backward(self._handle, stream), 'tedm_unet_pack_backward')
+                self._bwd_fingerprint = self._fingerprint
+            self.grad_views(dev)
+            self._train_x = x.detach().float().contiguous()          # the stem's weight gradient reads it
+            tin = None
+            if timestep is not None:
+                tin = timestep.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if tin.numel() != B:
+                    raise ValueError(f'timestep must have {B} elements, got {tin.numel()}')
+            need = L.tedm_unet_train_workspace_bytes(self._handle, B, H, W)
+            if need == 0:
+                _lib.check(-1, f'training workspace sizing for input {tuple(x.shape)}')
+            if self._train_ws is None or self._train_ws.numel() < need or self._train_ws.device != dev:
+                self._train_ws = None
+                self._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            eps = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=dev)
+            _lib.check(L.tedm_unet_forward_train(
+                self._handle, self._train_x.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
+                eps.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(), stream, self._flags(False, False)),
+                'tedm_unet_forward_train')
+        return eps
+
+    def native_backward(self, d_eps: Tensor) -> Dict[str, Tensor]:
+        """Backward of the last `native_forward_train`; overwrites `grad_flat` and returns its views."""
+        L = _lib.lib()
+        dev = d_eps.device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            g = d_eps.detach().float().contiguous()
+            _lib.check(L.tedm_unet_backward(self._handle, g.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(),
+                                            stream), 'tedm_unet_backward')
+        return self._grad_views
+
     def _read_trace(self) -> Dict[str, Tensor]:
         L = _lib.lib()
         out = {}
@@ -336,6 +425,11 @@ class Unet(nn.Module):
         return out
 
     def forward(self, x: Tensor, timestep: Optional[Tensor] = None, cond: Optional[Tensor] = None) -> Tensor:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if x.requires_grad:
+                raise NotImplementedError('tedm_amd.Unet: gradients w.r.t. the input image are not computed')
+            names, params = zip(*self.named_parameters())
+            return _UnetTrainFn.apply(self, x, timestep, names, *params)
         hooked = any(len(lvl[2]._forward_hooks) or len(lvl[2]._forward_pre_hooks) for lvl in self.ups)
         eps, taps = self.native_forward(x, timestep, want_taps=hooked)
         if hooked:
