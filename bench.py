@@ -101,6 +101,33 @@ def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):
         dist.destroy_process_group()
 
 
+def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
+    """BASELINE config 4: one optimizer step of trainers/train_base_diffusion.py:36-47 per GPU-local batch
+    (q-sample, recorded UNet forward, L1/p2 loss, full backward as HIP kernels), ONE all-reduce of the flat
+    gradient buffer (RCCL) and a fused Adam update.  Weak scaling: B images per GPU."""
+    import torch
+    dm.train()
+    opt = torch.optim.Adam(dm.model.parameters(), lr=1e-4, fused=True)
+    tr = dp.DataParallelTrainer(dm, opt, dist)
+    B, S = x0.shape[0], x0.shape[-1]
+
+    def step():
+        return tr.step(x0, t=t, noise=noise)
+    elapsed, loss = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'train-step images/sec @256x256 (fwd + bwd + grad all-reduce + Adam)',
+            'value': round(world * B * args.steps / elapsed, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
+            'config': {'workload': f'DiffusionModel.train_step + backward + Adam, {B}x1x{S}x{S} per GPU, global batch {B * world} '
+                                   f'(BASELINE configs[3])', 'final_loss': round(float(loss), 6),
+                       'train_workspace_GiB': round(dm.model._train_ws.numel() / 2 ** 30, 2)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -109,7 +136,7 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
-    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract'],
+    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
@@ -161,6 +188,8 @@ def main() -> None:
 
     if args.mode == 'extract':
         return bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise)
+    if args.mode == 'train':
+        return bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise)
 
     def sync_all():
         dp.barrier(dist, dev)

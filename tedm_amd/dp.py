@@ -83,3 +83,43 @@ def timed_steps(step, steps: int, warmup: int, dist=None, device: Optional[torch
         out = step()
     barrier(dist, device)
     return max_over_ranks(dist, time.perf_counter() - t0, device), out
+
+
+# ---- data-parallel training (BASELINE.json config 4; trainers/train_base_diffusion.py under DDP) ----------
+def allreduce_grads_(dist, flat: torch.Tensor, local_n: int, global_n: int) -> torch.Tensor:
+    """Turn per-rank gradients of LOCAL-batch-mean losses into the gradient of the GLOBAL-batch-mean loss.
+
+    Each rank's `flat` holds d(mean over its local_n samples)/d(params).  The global mean over
+    global_n = sum(local_n) samples is sum_r (local_n_r / global_n) * local_mean_r, so the buffer is scaled by
+    local_n / global_n and summed over ranks: ONE all-reduce of the whole flat gradient buffer (RCCL ring
+    over xGMI on GPUs, gloo on CPU) -- no per-tensor buckets, the backward writes straight into `flat`."""
+    if dist is None:
+        return flat
+    if local_n != global_n:
+        flat.mul_(local_n / float(global_n))
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+class DataParallelTrainer:
+    """One optimizer step of trainers/train_base_diffusion.py:23-47 with the image batch sharded over ranks.
+
+    `dm` is a tedm_amd.DiffusionModel on this rank's GPU; every rank holds a full replica, runs the native
+    forward+backward on its shard, all-reduces `dm.model.grad_flat` once and applies the same optimizer
+    update (so replicas stay bit-identical when the collective is deterministic)."""
+
+    def __init__(self, dm, optimizer, dist=None):
+        self.dm, self.opt, self.dist = dm, optimizer, dist
+
+    def step(self, x_local: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+             global_batch: Optional[int] = None) -> torch.Tensor:
+        n = x_local.shape[0]
+        world = self.dist.get_world_size() if self.dist is not None else 1
+        gb = global_batch if global_batch is not None else n * world
+        loss = self.dm.train_step_native(x_local, t=t, noise=noise)
+        allreduce_grads_(self.dist, self.dm.model.grad_flat, n, gb)
+        self.opt.step()
+        if self.dist is not None:                      # report the global-batch loss like a DDP trainer's log line
+            loss = loss * (n / float(gb))
+            self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM)
+        return loss

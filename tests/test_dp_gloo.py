@@ -56,3 +56,51 @@ def test_two_rank_gloo_timing_and_aggregation():
     assert (b0, e0, b1, e1) == (0, 51, 51, 101)
     assert tot0 == tot1 == float(sum(range(101))) and n0 == n1 == 101.0
     assert t0 == t1 and t0 >= 3 * 0.02 * 0.9                # both ranks report the slower rank's time
+
+
+def _grad_worker(rank, world, port, q):
+    """Ragged shards (5 samples over 2 ranks): local-mean gradients from the CPU oracle, combined with the
+    product's all-reduce helper, must equal the global-batch gradient."""
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    torch.set_num_threads(2)
+    from oracle import unet_ref as O
+    from tedm_amd import dp
+    from tedm_amd.weights import synth_state_dict
+    dist = dp.init('gloo')
+    gen = torch.Generator().manual_seed(3)
+    N, S, dim = 5, 16, 32
+    x0, noise = torch.rand(N, 1, S, S, generator=gen), torch.randn(N, 1, S, S, generator=gen)
+    t = torch.randint(0, 1000, (N,), generator=gen)
+    bufs = O.diffusion_buffers()
+    from tedm_amd.unet import Unet
+    m = Unet(dim)                                   # host-side container only: shapes of the 276 keys
+    w = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1)
+
+    def grads(sl):
+        p = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+        with torch.enable_grad():
+            O.train_loss(p, bufs, x0[sl], t[sl], noise[sl], normalize=True, dim=dim).backward()
+        return torch.cat([p[k].grad.reshape(-1) for k in sorted(p)])
+    beg, end = dp.shard_range(N, world, rank)
+    flat = grads(slice(beg, end))
+    dp.allreduce_grads_(dist, flat, end - beg, N)
+    full = grads(slice(0, N))
+    q.put((rank, float((flat - full).norm() / full.norm())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_equals_global_batch():
+    world, port = 2, 29633
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(err < 1e-5 for _, err in res), res
