@@ -145,15 +145,25 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __rest
     }
 }
 
-// out[c] (+)= sum_n in[n][c]   (B <= a few hundred)
-__global__ void sum_over_batch_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out, int accumulate,
-                                      int stride = 0) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_n in[n*stride + c], n < R (partial rows of the split reductions; R up to a few thousand).
+// One block = 64 columns x 16 row lanes; fixed summation order => deterministic.
+__global__ __launch_bounds__(1024) void sum_over_batch_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out,
+                                                              int accumulate, int stride = 0) {
+    __shared__ double red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     if (stride == 0) stride = C;
     double s = 0.0;
-    for (int n = 0; n < B; ++n) s += in[(size_t)n * stride + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    if (c < C)
+        for (int n = rl; n < R; n += 16) s += in[(size_t)n * stride + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
 }
 
 // Pass B: dy = ca*du - M0r - xhat*M1r
@@ -305,14 +315,36 @@ __global__ void linear_bwd_w_kernel(const float* __restrict__ dy, const float* _
     dW[i] = accumulate ? dW[i] + s : s;
     if (k == 0 && db) db[j] = accumulate ? db[j] + sb : sb;
 }
-__global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int B, int J, int K,
-                                    int dy_stride, float* __restrict__ dx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * K) return;
-    const int b = i / K, k = i - b * K;
-    float s = 0.f;
-    for (int j = 0; j < J; ++j) s = fmaf(dy[(size_t)b * dy_stride + j], W[(size_t)j * K + k], s);
-    dx[i] = s;
+// dx partial: block (kb, js) handles 64 columns k and the j-range [js*jpb, (js+1)*jpb) for every b (W row read once,
+// reused for all B <= 32*LB_NB rows).  part[js][b][k]; summed by sum_over_batch_kernel.
+constexpr int LB_MAXB = 32;
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int B, int J, int K,
+                                                           int dy_stride, int jpb, int b0, float* __restrict__ part) {
+    __shared__ float red[4][LB_MAXB][64];
+    const int kl = threadIdx.x & 63, jw = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    const int jb = blockIdx.y * jpb, je = (jb + jpb < J) ? jb + jpb : J;
+    const int nb = (B - b0) < LB_MAXB ? (B - b0) : LB_MAXB;
+    float acc[LB_MAXB];
+#pragma unroll
+    for (int b = 0; b < LB_MAXB; ++b) acc[b] = 0.f;
+    const int kc = k < K ? k : K - 1;
+    for (int j = jb + jw; j < je; j += 4) {
+        const float w = W[(size_t)j * K + kc];
+#pragma unroll
+        for (int b = 0; b < LB_MAXB; ++b) {
+            const int bb = b < nb ? b0 + b : b0;
+            acc[b] = fmaf(dy[(size_t)bb * dy_stride + j], w, acc[b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < LB_MAXB; ++b) red[jw][b][kl] = acc[b];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * 64; i += 256) {
+        const int b = i >> 6, kk = i & 63;
+        if (blockIdx.x * 64 + kk < K)
+            part[((size_t)blockIdx.y * B + b0 + b) * K + blockIdx.x * 64 + kk] = (red[0][b][kk] + red[1][b][kk]) + (red[2][b][kk] + red[3][b][kk]);
+    }
 }
 // g *= act'(pre):  mode 0 SiLU (pre = input of the SiLU), mode 1 exact-erf GELU
 __global__ void act_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n, int mode) {
@@ -517,10 +549,10 @@ int op_gn_silu_backward(const float* G, const float* y, const float* fa, const f
     DISPATCH_V(m.v, gn_bwd_reduce_kernel, dim3(E, B), dim3(256), 0, st, G, y, fa, fb, mr, groups, hw, C, m.lpp, ppb, slab);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * groups), dim3(64), 0, st, slab, E, C, groups, hw, mr, gamma, beta, film,
                        film_stride, dfilm, ca, mcoef, dgam_n, dbet_n, dbias_n);
-    const int cb = (C + 255) / 256;
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dgam_n, B, C, dgamma, accumulate);
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dbet_n, B, C, dbeta, accumulate);
-    if (dbias) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(256), 0, st, dbias_n, B, C, dbias, accumulate);
+    const int cb = (C + 63) / 64;
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dgam_n, B, C, dgamma, accumulate);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dbet_n, B, C, dbeta, accumulate);
+    if (dbias) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dbias_n, B, C, dbias, accumulate);
     const long long P = (long long)B * hw;
     long long waves = (P + (64 / m.lpp) - 1) / (64 / m.lpp), blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
@@ -544,7 +576,7 @@ int op_ln_backward(const float* dY, const float* x, const float* g, const float*
     if (!pixmap(C, m)) return TEDM_EINVAL;
     const int nb = ln_bwd_blocks(P, C);
     DISPATCH_V(m.v, ln_bwd_kernel, dim3(nb), dim3(256), 0, st, dY, x, g, add, dx, part, P, C, m.lpp);
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, dg, accumulate);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, nb, C, dg, accumulate);
     return LAUNCH_OK();
 }
 
@@ -554,15 +586,23 @@ int op_colsum(const float* x, float* part, float* out, int accumulate, long long
     if (!pixmap(C, m)) return TEDM_EINVAL;
     const int nb = ln_bwd_blocks(P, C);
     DISPATCH_V(m.v, colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C, m.lpp);
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, out, accumulate);
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, nb, C, out, accumulate);
     return LAUNCH_OK();
 }
 
+int linear_bwd_splits(int J) { int s = J / 64; return s < 1 ? 1 : (s > 128 ? 128 : s); }
+// part: linear_bwd_splits(J)*B*K floats (only when dx is requested)
 int op_linear_backward(const float* dy, int dy_stride, const float* x, const float* W, int B, int J, int K, float* dW, float* db,
-                       float* dx, int accumulate, hipStream_t st) {
+                       float* dx, float* part, int accumulate, hipStream_t st) {
     if (dW) hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)(((long long)J * K + 255) / 256)), dim3(256), 0, st, dy, x, B, J, K,
                                dy_stride, dW, db, accumulate);
-    if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, dy, W, B, J, K, dy_stride, dx);
+    if (dx) {
+        if (!part) return TEDM_EINVAL;
+        const int S = linear_bwd_splits(J), jpb = (J + S - 1) / S;
+        for (int b0 = 0; b0 < B; b0 += LB_MAXB)
+            hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((K + 63) / 64, S), dim3(256), 0, st, dy, W, B, J, K, dy_stride, jpb, b0, part);
+        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((B * K + 63) / 64), dim3(1024), 0, st, part, S, B * K, dx, 0, 0);
+    }
     return LAUNCH_OK();
 }
 int op_act_backward(float* g, const float* pre, int n, int mode, hipStream_t st) {
@@ -587,9 +627,9 @@ int op_final_conv_backward(const float* dY_nchw, const float* x, const float* w,
     DISPATCH_V(m.v, final_conv_bwd_kernel, dim3(nb), dim3(256), 0, st, dY_nchw, x, w, dx, part, P, hw, C, OD, m.lpp);
     // part rows are [o][C+1]: treat as nb x (OD*(C+1)) and sum over blocks, then split into dw / db on the fly
     for (int o = 0; o < OD; ++o) {
-        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part + (size_t)o * (C + 1), nb, C,
+        hipLaunchKernelGGL(sum_over_batch_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part + (size_t)o * (C + 1), nb, C,
                            dw + (size_t)o * C, accumulate, OD * (C + 1));
-        if (db) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(1), dim3(64), 0, st, part + (size_t)o * (C + 1) + C, nb, 1, db + o,
+        if (db) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(1), dim3(1024), 0, st, part + (size_t)o * (C + 1) + C, nb, 1, db + o,
                                    accumulate, OD * (C + 1));
     }
     return LAUNCH_OK();

@@ -55,10 +55,17 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
                   int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
                   float* dw, int accumulate, hipStream_t st);
 
+// wgrad_mfma.hip (bf16x3 matrix-core path for stride-1 3x3 / 1x1; called by op_conv_wgrad)
+size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo);
+int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
+                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, hipStream_t st);
+int wgrad_set_tuning(const char* key, int v);
+
 // backward.hip
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st);
+int linear_bwd_splits(int J);
 int op_linear_backward(const float* dy, int dy_stride, const float* x, const float* W, int B, int J, int K, float* dW, float* db,
-                       float* dx, int accumulate, hipStream_t st);
+                       float* dx, float* part /*linear_bwd_splits(J)*B*K floats when dx*/, int accumulate, hipStream_t st);
 int op_act_backward(float* g, const float* pre, int n, int mode /*0 silu, 1 gelu*/, hipStream_t st);
 int op_add2(const float* a, const float* b, float* out, long long n, hipStream_t st);
 int final_conv_bwd_blocks(long long P);

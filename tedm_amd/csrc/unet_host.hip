@@ -823,6 +823,7 @@ int tedm_set_tuning(const char* key, int value) {
     g_err[0] = 0;
     if (!key) return fail(TEDM_EINVAL, "null key");
     if (!strcmp(key, "la_fused") && (value == 0 || value == 1)) { g_la_fused = value; return TEDM_OK; }
+    if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
 }

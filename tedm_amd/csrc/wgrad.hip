@@ -9,6 +9,8 @@
 // (dY tile + haloed X tile staged in LDS as fp32, X through the same GN+FiLM+SiLU / LayerNorm prologue
 // as the forward conv), keeps the per-tap 32x32 accumulators in registers and writes ONE partial block;
 // a second kernel sums the pixel splits in fixed order (deterministic, no atomics) into OIHW.
+#include <string.h>
+
 #include "common.h"
 #include "ops.h"
 #include "../../include/tedm_hip.h"
@@ -140,19 +142,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[co][ci][tap] (+)= sum_s part[s][tap][co][ci]  (fixed order over s => deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int T, int Cout, int Cin, float* __restrict__ dw,
-                                    int accumulate) {
+// dW[co][ci][tap] (+)= sum_s part[s][tap][co][ci]  (fixed order over s => deterministic).
+// One block = 64 consecutive (tap,co,ci) entries x 16 split lanes.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int S, int T, int Cout, int Cin,
+                                                            float* __restrict__ dw, int accumulate) {
+    __shared__ float red[16][64];
     const long long per = (long long)T * Cout * Cin;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per) return;
+    const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + il;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * per + i];
-    const int ci = (int)(i % Cin);
-    const long long r = i / Cin;
-    const int co = (int)(r % Cout), tap = (int)(r / Cout);
-    float* o = dw + ((size_t)co * Cin + ci) * T + tap;
-    *o = accumulate ? *o + s : s;
+    if (i < per)
+        for (int k = sl; k < S; k += 16) s += part[(size_t)k * per + i];
+    red[sl][il] = s;
+    __syncthreads();
+    if (sl == 0 && i < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][il];
+        const int ci = (int)(i % Cin);
+        const long long r = i / Cin;
+        const int co = (int)(r % Cout), tap = (int)(r / Cout);
+        float* o = dw + ((size_t)co * Cin + ci) * T + tap;
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 template <int KH, int KW, int STRIDE, int PAD, int UPS, int TR, int NTAP, int PRO>
@@ -191,10 +203,21 @@ static void wgrad_geometry(int k, int stride, int Cout, int Cin, int B, int Ho, 
     (void)k;
 }
 
+static int g_wgrad_mfma = 1;   // tedm_set_tuning("wgrad_mfma", 0|1): bf16x3 matrix-core path vs the exact-fp32 MFMA kernel
+int wgrad_set_tuning(const char* key, int v) {
+    if (!strcmp(key, "wgrad_mfma") && (v == 0 || v == 1)) { g_wgrad_mfma = v; return TEDM_OK; }
+    return TEDM_EINVAL;
+}
+
 size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo) {
     int TR, tx, ty, S, tpw;
     wgrad_geometry(k, stride, Cout, Cin, B, Ho, Wo, &TR, &tx, &ty, &S, &tpw);
-    return (size_t)S * k * k * Cout * Cin;
+    size_t n = (size_t)S * k * k * Cout * Cin;
+    if (stride == 1 && (k == 1 || k == 3)) {                       // sized for either path (the switch is a runtime tuning key)
+        const size_t m = wgrad_mfma_floats(k, Cout, Cin, B, Ho, Wo);
+        if (m > n) n = m;
+    }
+    return n;
 }
 
 // dw (OIHW, Cout x (C1+C2) x k x k) = [accumulate ? dw : 0] + wgrad.  ups: 1 = the conv saw the nearest-x2 upsampled input.
@@ -206,6 +229,15 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     WgradArgs a{};
     a.dy = dy; a.Cout = Cout; a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.pro_a = pro_a; a.pro_b = pro_b; a.part = part;
+    if (g_wgrad_mfma && stride == 1 && (k == 1 || k == 3)) {
+        int S = 0;
+        const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, st);
+        if (rc != TEDM_OK) return rc;
+        const long long per = (long long)k * k * Cout * Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(1024), 0, st, part, S, k * k, Cout, Cin, dw,
+                           accumulate);
+        return LAUNCH_OK();
+    }
     int TR;
     wgrad_geometry(k, stride, Cout, Cin, B, Ho, Wo, &TR, &a.tiles_x, &a.tiles_y, &a.S, &a.tpw);
     int rc = TEDM_EINVAL;
@@ -217,7 +249,7 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     else if (k == 1 && stride == 1 && !ups && pro == PRO_LN) rc = launch_wgrad<1, 1, 1, 0, 0, 2, 1, PRO_LN>(a, st);
     if (rc != TEDM_OK) return rc;
     const long long per = (long long)k * k * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, part, a.S, k * k, Cout, Cin, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(1024), 0, st, part, a.S, k * k, Cout, Cin, dw,
                        accumulate);
     return LAUNCH_OK();
 }
