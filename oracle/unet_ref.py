@@ -251,6 +251,21 @@ def train_loss(p: Params, bufs: Dict[str, Tensor], x0: Tensor, t: Tensor, noise:
     return (loss * bufs['p2_loss_weight'].gather(-1, t)).mean()
 
 
+def p_mean_variance(p: Params, bufs: Dict[str, Tensor], x_t: Tensor, t: Tensor, percentile: float = 0.995,
+                    clip_denoised: bool = True, **kw) -> Tuple[Tensor, Tensor, Tensor]:
+    """models/diffusion_model.py:221-267 (objective pred_noise): eps -> x0 (:269-285), per-sample
+    `percentile` dynamic thresholding (:224-231), posterior mean / clipped log-variance (:259-267)."""
+    eps = unet_forward(p, x_t, t, **kw)
+    take = lambda name: bufs[name].gather(-1, t).reshape(-1, 1, 1, 1)
+    x0 = take('sqrt_recip_alphas_cumprod') * x_t - take('sqrt_recipm1_alphas_cumprod') * eps
+    if clip_denoised:
+        s = torch.quantile(x0.flatten(1).abs(), percentile, dim=1)
+        s = torch.max(s, torch.tensor(1.0))[:, None, None, None]
+        x0 = torch.clip(x0, -s, s) / s
+    mean = take('posterior_mean_coef1') * x0 + take('posterior_mean_coef2') * x_t
+    return mean, take('posterior_log_variance_clipped'), x0
+
+
 def extract_features(p: Params, bufs: Dict[str, Tensor], x0: Tensor, steps: Sequence[int],
                      noise: Tensor, **kw) -> Tensor:
     """models/datasetDM_model.py:67-83 -- for every t in steps: q-sample the UN-normalised

@@ -203,3 +203,44 @@ class DiffusionModel(nn.Module):
         mean, logvar, _ = self.p_mean_variance(x_t, bt, cond=cond)
         noise = torch.randn_like(x_t) if t > 0 else 0.
         return mean + (0.5 * logvar).exp() * noise
+
+    # -- whole reverse chain (trainers/utils.py:62-98 `sample_plot_image` without the plotting) -------------
+    def _sample_step_tensor(self, x_t: Tensor, bt: Tensor, cond: Optional[Tensor] = None) -> Tensor:
+        """`sample_timestep` with the timestep as a device tensor (no host branch on t, so the step can be
+        captured in a hipGraph): the noise term is masked where t == 0 instead of being skipped."""
+        mean, logvar, _ = self.p_mean_variance(x_t, bt, cond=cond)
+        noise = torch.randn_like(x_t) * (bt > 0).to(x_t.dtype).view(-1, 1, 1, 1)
+        return mean + (0.5 * logvar).exp() * noise
+
+    @torch.no_grad()
+    def sample(self, batch: int, img_size: int, channels: Optional[int] = None, cond: Optional[Tensor] = None,
+               steps: Optional[int] = None, use_graph: bool = True, x_T: Optional[Tensor] = None) -> Tensor:
+        """Ancestral sampling x_T -> x_0 over `steps` (default all `timesteps`) serial denoise steps on ONE GPU
+        (the chain does not shard).  The chain is latency bound at small batch (~300 kernel launches
+        per UNet forward), so one step is captured once as a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed
+        with the timestep held in a device tensor."""
+        dev = next(self.parameters()).device
+        ch = channels if channels is not None else self.model.channels
+        x = x_T.clone() if x_T is not None else torch.randn(batch, ch, img_size, img_size, device=dev)
+        T = steps if steps is not None else self.timesteps
+        bt = torch.zeros(batch, dtype=torch.long, device=dev)
+        if not use_graph:
+            for t in reversed(range(T)):
+                bt.fill_(t)
+                x = self._sample_step_tensor(x, bt, cond)
+            return x
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                     # warm-up off the default stream: packs weights, sizes the workspace
+            bt.fill_(T - 1)
+            for _ in range(2):
+                self._sample_step_tensor(x, bt, cond)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._sample_step_tensor(x, bt, cond)
+        for t in reversed(range(T)):
+            bt.fill_(t)
+            graph.replay()
+            x.copy_(out)
+        return x

@@ -82,3 +82,14 @@ def test_classifier_and_loss(golden_dir):
     gl = np.load(golden_dir / 'loss_d64_s64.npz')
     loss = O.train_loss(w, bufs, torch.from_numpy(gl['x0']), torch.from_numpy(gl['t']), torch.from_numpy(gl['noise']))
     assert abs(float(loss) - float(gl['loss'])) < 1e-5
+
+
+def test_sampler_p_mean_variance(golden_dir):
+    """models/diffusion_model.py:221-267 at t in {999, 500, 0}; dynamic threshold s > 1 and s clamped to 1."""
+    g = np.load(golden_dir / 'sampler_d64_s32.npz')
+    assert g['s'][0] > 1.0 and g['s'][2] < 1.0
+    mean, logvar, x0 = O.p_mean_variance(weights(golden_dir, 64, 0), O.diffusion_buffers(), torch.from_numpy(g['x_t']),
+                                         torch.from_numpy(g['t']))
+    assert rel(mean, g['mean']) < 1e-6 and rel(x0, g['x0']) < 1e-6
+    assert torch.equal(logvar.reshape(-1), torch.from_numpy(g['logvar']))
+    assert rel(mean[2:3], g['x_prev_t0']) < 1e-6        # sample_timestep(t=0) adds no noise
