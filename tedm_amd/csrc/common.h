@@ -88,6 +88,8 @@ struct ConvArgs {
     int tpw;                       // spatial tiles per workgroup (filled by the launcher)
     int nk16;                      // (C1+C2)/16
     int prec;                      // TEDM_PREC_*
+    int prio_mode;                 // 0 none, 1: waves in even SIMD slots run at s_setprio 1 (filled by the launcher)
+    unsigned long long* trace;     // diagnostic builds (-DTEDM_DIAG_TRACE) only: per-wave phase timestamps
 };
 
 int conv_launch(const ConvArgs& a, int KH, int stride, int ups, int pro, hipStream_t st);

@@ -63,6 +63,18 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
+    // Two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe.  Left alone they run in
+    // lockstep (both in their MFMA segment at half speed, then both in staging / epilogue with the pipe idle:
+    // measured with the diagnostic stamps).  A static priority for the wave in the even hardware slot turns the
+    // pair into a pipeline: the prioritised wave runs its MFMA segments at full rate and the other one fills
+    // the pipe during its partner's staging, barrier and epilogue phases.
+    if (a.prio_mode == 1) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
+        if ((slot & 1) == 0) __builtin_amdgcn_s_setprio(1);
+    } else if (a.prio_mode == 2) {
+        if ((blockIdx.x & 1) == 0) __builtin_amdgcn_s_setprio(1);
+    }
+
     // Block order: 1-D grid over (group of a.tpw consecutive spatial tiles, cout-tile group).  Workgroups
     // that read the SAME input tiles (different cout groups) get block ids 8 apart -- the dispatcher deals
     // blocks round-robin over the 8 XCDs, so they land on one XCD back to back and share the halo through
@@ -195,21 +207,23 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     constexpr int NSET = KW > 1 ? KW : 2;
     uint4 bq[NSET][KH][KS][NPB];
 
+    // Inactive waves (cout group past the end) run the same straight-line code on the last valid group and
+    // skip only the epilogue: any branch inside the chunk loop splits it into basic blocks, and the waitcnt
+    // pass then guards every MFMA group with `s_waitcnt vmcnt(0)`, which throws the prefetch distance away.
+    const int ctw = active ? ct : CT - 1;
     auto load_b = [&](int c, int kx, uint4 (&b)[KH][KS][NPB]) {
-        if (!active) return;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int p = 0; p < NPB; ++p)   // packed layout always carries both planes (hi, lo)
-                    b[ky][ks][p] = wq[((((size_t)ct * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];
+                    b[ky][ks][p] = wq[((((size_t)ctw * a.nk16 + (c * KS + ks)) * T + (ky * KW + kx)) * 2 + p) * 64 + lane];
     };
 
     // All MFMAs of tap column kx for one staged chunk.  Each halo row is read from LDS once and feeds
     // every ky whose output row it belongs to.
     auto compute_kx = [&](int buf, int kx, const uint4 (&b)[KH][KS][NPB]) {
-        if (!active) return;
         const char* sb = smem + buf * G::BUFSZ + lane_a;
         constexpr int NPR = MT + (KH - 1) / STRIDE;           // plane rows touched by one row parity
 #pragma unroll
@@ -332,19 +346,34 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
             for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     };
 
+#ifdef TEDM_DIAG_TRACE
+    auto stamp = [&](int ev) {
+        if (a.trace && lane == 0 && blockIdx.x < 2048 && ev < 64)
+            a.trace[((size_t)blockIdx.x * 4 + (wave & 3)) * 64 + ev] = __builtin_readcyclecounter();
+    };
+    if (a.trace && lane == 0 && blockIdx.x < 2048) {
+        stamp(0);
+        a.trace[((size_t)blockIdx.x * 4 + (wave & 3)) * 64 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+#else
+    auto stamp = [&](int) {};
+#endif
     if (NBUF == 2) {
         // weight groups are fetched PD groups ahead (two tap columns ~ 2 x 36 MFMAs of cover for the L2
         // latency); the sequence simply wraps to chunk 0 at a tile boundary (same weights, next tile)
         constexpr int PD = KW > 1 ? 2 : 1;
         const int total = tile_cnt * NC;                      // flattened (tile, chunk) iterations
-        auto chunk_body = [&](int c, int buf, bool more) {
+        // VMEM returns in order (vmcnt): the next chunk's ACTIVATION loads are issued after the last weight
+        // group this chunk still has to wait for (the kx=0 prefetch of tap column PD), so no MFMA of this
+        // chunk waits behind them; they only have to land by write_lds at the end of the chunk.
+        auto chunk_body = [&](int c, int buf, int c_next, bool stage_next) {
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
                 const int kx2 = (kx + PD) % KW;
                 int c2 = c + (kx + PD) / KW;
-                const bool wrap = c2 >= NC;
-                if (wrap) c2 -= NC;
-                if (!wrap || more) load_b(c2, kx2, bq[kx2 % NSET]);
+                if (c2 >= NC) c2 -= NC;                        // wraps to the next tile's chunk 0 (same weights); at the very
+                load_b(c2, kx2, bq[kx2 % NSET]);               // end of the workgroup the wrapped group is loaded and unused
+                if (kx == (KW > PD ? KW - 1 - PD : 0) && stage_next) issue_loads(c_next);
                 compute_kx(buf, kx, bq[kx % NSET]);
             }
         };
@@ -354,20 +383,23 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
         issue_loads(0);
         write_lds(0);
         __syncthreads();
+        stamp(2);
         int c = 0, tl = tile_beg;
         for (int it = 0; it < total; ++it) {
             const bool more = it + 1 < total;
             const bool last_chunk = c == NC - 1;
-            if (more) {
-                if (last_chunk) setup_tile(tl + 1);           // the next iteration stages a new tile
-                issue_loads(last_chunk ? 0 : c + 1);
-            }
+            if (more && last_chunk) setup_tile(tl + 1);       // the next iteration stages a new tile
             if (c == 0) zero_acc();
-            chunk_body(c, it & 1, !last_chunk || more);
+            stamp(4 + 4 * it);
+            chunk_body(c, it & 1, last_chunk ? 0 : c + 1, more);
+            stamp(5 + 4 * it);
             if (more) write_lds((it + 1) & 1);
+            stamp(6 + 4 * it);
             __syncthreads();
+            stamp(7 + 4 * it);
             if (last_chunk) { epilogue(tl); ++tl; c = 0; } else ++c;
         }
+        stamp(3);
     } else {
         // single LDS buffer (1x1, HBM-bound): keep registers low so 3-4 workgroups share a CU and
         // overlap each other's load / MFMA phases; the chunk's weights travel with its activations.
@@ -397,6 +429,7 @@ struct TileSel { int wm, wn, mt; };
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
 int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
 int g_tile_narrow = 1;
+int g_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
 int g_tpw_max = 1;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
 int g_xcd_order = 1;      // 1: cout-tile groups of one input tile share an XCD (tedm_set_tuning("conv_xcd_order", v))    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
 
@@ -434,6 +467,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     if (tpw > g_tpw_max) tpw = g_tpw_max;
     if (tpw < 1) tpw = 1;
     b.tpw = tpw;
+    b.prio_mode = g_prio_mode;
     dim3 grid(((ntile + tpw - 1) / tpw) * b.ny);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, b);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
@@ -469,6 +503,7 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_prio") && v >= 0 && v <= 2) { g_prio_mode = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }

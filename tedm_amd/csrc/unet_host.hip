@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -855,7 +856,26 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
         a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b; a.stats = stats; a.stats_mode = stats ? stats_mode : STATS_NONE;
         a.prec = prec;
         if (stats_entries) *stats_entries = conv_stats_entries(k, stride, Cout, Ho, Wo);
+#ifdef TEDM_DIAG_TRACE
+        const char* tf = getenv("TEDM_TRACE_FILE");
+        const size_t tbytes = (size_t)2048 * 4 * 64 * 8;
+        if (tf) {
+            rc = conv_launch(a, k, stride, upsample, pro, st);           // warm-up (clocks, caches)
+            if (hipMalloc((void**)&a.trace, tbytes) != hipSuccess) return fail(TEDM_ENOMEM, "trace alloc");
+            (void)hipMemsetAsync(a.trace, 0, tbytes, st);
+        }
+#endif
         rc = conv_launch(a, k, stride, upsample, pro, st);
+#ifdef TEDM_DIAG_TRACE
+        if (tf && a.trace) {
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> hbuf(tbytes / 8);
+            (void)hipMemcpy(hbuf.data(), a.trace, tbytes, hipMemcpyDeviceToHost);
+            FILE* f = fopen(tf, "wb");
+            if (f) { fwrite(hbuf.data(), 1, tbytes, f); fclose(f); }
+            (void)hipFree(a.trace);
+        }
+#endif
     }
     (void)hipStreamSynchronize(st);
     (void)hipFree(wpk);
