@@ -128,6 +128,62 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
         dist.destroy_process_group()
 
 
+def bench_tedm(args, dm, dp, dist, dev, world, rank):
+    """BASELINE config 5 shape: TEDM = frozen diffusion UNet + pixel-classifier head trained with BCE
+    (trainers/train_datasetDM.py), JSRT-shaped synthetic data (B,1,128,128) + binary masks, the 8 TEDM timesteps
+    (train.py:47).  One step = T UNet forwards (taps only) + head forward/backward + Adam on the head; the head's first
+    layer runs fused at the taps' native resolution (tedm_amd/head.py).  The unfused reference formulation
+    (materialised (B, 960*T, S, S) features) is timed next to it."""
+    import torch
+    import torch.nn.functional as F
+    from tedm_amd import DatasetDM, load_synth_weights
+    steps = [1, 10, 25, 50, 200, 400, 600, 800]
+    B, S = args.batch, 128
+    ddm = DatasetDM(Namespace(normalize=True, dim=64, saved_diffusion_model='/nonexistent', verbose=False, device='cuda',
+                              t_steps_to_save=steps, max_images_per_forward=64))
+    ddm.diffusion_model = dm
+    load_synth_weights(ddm.classifier, seed=5)
+    ddm = ddm.to(dev).train()
+    dm.eval()
+    g = torch.Generator().manual_seed(99 + rank)
+    x = torch.rand(B, 1, S, S, generator=g).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing='ij')
+    mask = ((((yy - 64) / 40.) ** 2 + ((xx - 40) / 22.) ** 2 < 1) | (((yy - 64) / 40.) ** 2 + ((xx - 88) / 22.) ** 2 < 1)).float()
+    y = mask[None, None].expand(B, 1, S, S).contiguous().to(dev)                 # two blobs, like a lung mask
+    opt = torch.optim.Adam(ddm.classifier.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        loss = F.binary_cross_entropy_with_logits(ddm(x), y)
+        loss.backward()
+        if dist is not None:
+            for p in ddm.classifier.parameters():
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                p.grad.div_(world)
+        opt.step()
+        return loss.detach()
+    res = {}
+    for fused in (False, True):
+        ddm.fused_head = fused
+        torch.cuda.reset_peak_memory_stats(dev)
+        elapsed, loss = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
+        res[fused] = (elapsed, float(loss), torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+    if rank == 0:
+        el, loss, mem = res[True]
+        print(json.dumps({
+            'metric': 'TEDM head train-step images/sec @128x128, 8 timesteps (frozen UNet x8 + fused head fwd/bwd + Adam)',
+            'value': round(world * B * args.steps / el, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * el / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
+            'config': {'workload': f'DatasetDM (TEDM) train step, {B}x1x{S}x{S} per GPU, t_steps={steps} (BASELINE configs[4] shape)',
+                       'final_loss': round(loss, 6), 'peak_mem_GiB': round(mem, 2),
+                       'unfused_ms_per_step': round(1e3 * res[False][0] / args.steps, 3),
+                       'unfused_peak_mem_GiB': round(res[False][2], 2)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -136,7 +192,7 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
-    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train'],
+    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
@@ -190,6 +246,8 @@ def main() -> None:
         return bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise)
     if args.mode == 'train':
         return bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise)
+    if args.mode == 'tedm':
+        return bench_tedm(args, dm, dp, dist, dev, world, rank)
 
     def sync_all():
         dp.barrier(dist, dev)

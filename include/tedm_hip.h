@@ -149,6 +149,28 @@ int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t
 int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const float* p2w, int T, int B,
                  long long chw, float* grad, float* scratch, float* loss, void* stream);
 
+/* ---- pixel-classifier head (models/datasetDM_model.py:57-64,85-88) -------------------
+ * The head's first layer is a 1x1 conv over the (B, 960*T, S, S) concat of nearest-upsampled decoder taps.  A 1x1 conv
+ * commutes with nearest upsampling and distributes over the channel concat:
+ *     W1 * cat_i(up(f_i)) = sum_i up(W1_i * f_i)
+ * so the projection runs at every tap's NATIVE resolution on the NHWC tap buffers the UNet forward already produced and
+ * the 960*T-channel tensor is never materialised (40 GB -> 1 GB at B=32, T=5, S=256).  These are the building blocks;
+ * tedm_amd/head.py wires them (and their adjoints) behind DatasetDM.forward. */
+size_t tedm_conv1x1_packed_bytes(int Cout, int Cin);                         /* 0 unless Cout%16==0 and Cin%32==0 */
+int tedm_conv1x1_pack(const float* w_out_in, int Cout, int Cin, void* wpk, int prec, void* stream);
+/* out (B,H,W,Cout) = x (B,H,W,Cin) * W^T [+ bias] [+ add]; `add` may alias `out` (accumulation over taps/timesteps). */
+int tedm_conv1x1_nhwc(const float* x, int B, int H, int W, int Cin, const void* wpk, int Cout, const float* bias,
+                      const float* add, float* out, int prec, void* stream);
+/* dw (Cout,Cin) (+)= sum_pixels dy^T x  (fp32 MFMA, deterministic split reduction). */
+size_t tedm_conv1x1_wgrad_workspace_bytes(int Cout, int Cin, int B, int H, int W);
+int tedm_conv1x1_wgrad_nhwc(const float* dy, const float* x, int B, int H, int W, int Cin, int Cout, float* dw,
+                            int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* out (B,S,S,C) = bias + sum_i nearest_upsample(z_i (B,h_i,w_i,C));  n <= 8 inputs. */
+int tedm_upsample_sum_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C,
+                           const float* bias, float* out, void* stream);
+/* adjoint of one nearest upsample by `factor`: out (B,h,w,C) = block sums of g (B,h*factor,w*factor,C). */
+int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, float* out, void* stream);
+
 const char* tedm_last_error(void);
 const char* tedm_version(void);
 

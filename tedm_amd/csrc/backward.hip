@@ -27,6 +27,45 @@ __global__ void pool2x2_sum_kernel(const float* __restrict__ g, float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Pixel-classifier head, first layer applied at the taps' native resolution:
+//   out[n][y][x][:] = bias + sum_i z_i[n][y*h_i/S][x*w_i/S][:]      (nearest upsample of every projected tap + sum)
+struct UpSumArgs { const float* z[8]; int h[8]; int w[8]; int n; };
+__global__ void upsample_sum_kernel(UpSumArgs a, const float* __restrict__ bias, float* __restrict__ out, int B, int S, int C,
+                                    long long total4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4)) * 4;
+        long long r = i / (C / 4);
+        const int x = (int)(r % S); r /= S;
+        const int y = (int)(r % S);
+        const int n = (int)(r / S);
+        float4 s = bias ? *(const float4*)(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < a.n; ++k) {
+            const int sy = (int)((long long)y * a.h[k] / S), sx = (int)((long long)x * a.w[k] / S);   // F.interpolate 'nearest'
+            const float4 v = *(const float4*)(a.z[k] + (((size_t)n * a.h[k] + sy) * a.w[k] + sx) * C + c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *(float4*)(out + (size_t)i * 4) = s;
+    }
+}
+// its adjoint: out[n][y][x][:] = sum over the f x f block of g that nearest-upsampling maps to (y,x)   (S = f*h)
+__global__ void pool_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int h, int w, int f, int C, long long total4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4)) * 4;
+        long long r = i / (C / 4);
+        const int x = (int)(r % w); r /= w;
+        const int y = (int)(r % h);
+        const int n = (int)(r / h);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) {
+                const float4 v = *(const float4*)(g + (((size_t)n * h * f + y * f + dy) * w * f + x * f + dx) * C + c4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        *(float4*)(out + (size_t)i * 4) = s;
+    }
+}
+
 TEDM_DEVFN float dsilu_f(float u) {            // d/du [u * sigmoid(u)]
     const float sg = 1.0f / (1.0f + __expf(-u));
     return sg * (1.0f + u * (1.0f - sg));
@@ -665,6 +704,26 @@ int op_l1_loss(const float* eps, const float* target, const long long* t, const 
     return LAUNCH_OK();
 }
 
+int op_upsample_sum(const float* const* z, const int* h, const int* w, int n, int B, int S, int C, const float* bias, float* out,
+                    hipStream_t st) {
+    if (n < 1 || n > 8 || C % 4) return TEDM_EINVAL;
+    UpSumArgs a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) { a.z[k] = z[k]; a.h[k] = h[k]; a.w[k] = w[k]; }
+    const long long total4 = (long long)B * S * S * (C / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(upsample_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, bias, out, B, S, C, total4);
+    return LAUNCH_OK();
+}
+int op_pool_sum(const float* g, float* out, int B, int h, int w, int f, int C, hipStream_t st) {
+    if (C % 4 || f < 1) return TEDM_EINVAL;
+    const long long total4 = (long long)B * h * w * (C / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pool_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, out, B, h, w, f, C, total4);
+    return LAUNCH_OK();
+}
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st) {
     if (C % 4) return TEDM_EINVAL;
     const long long total4 = (long long)B * h * w * (C / 4);

@@ -62,6 +62,9 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
 int wgrad_set_tuning(const char* key, int v);
 
 // backward.hip
+int op_upsample_sum(const float* const* z, const int* h, const int* w, int n, int B, int S, int C, const float* bias, float* out,
+                    hipStream_t st);
+int op_pool_sum(const float* g, float* out, int B, int h, int w, int f, int C, hipStream_t st);
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st);
 int linear_bwd_splits(int J);
 int op_linear_backward(const float* dy, int dy_stride, const float* x, const float* W, int B, int J, int K, float* dW, float* db,

@@ -781,6 +781,57 @@ int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const 
     return rc == TEDM_OK ? rc : fail(rc, "l1 loss launch failed");
 }
 
+// ---- pixel-classifier head building blocks (models/datasetDM_model.py:57-64,85-88) -------------
+size_t tedm_conv1x1_packed_bytes(int Cout, int Cin) { return (Cout % 16 || Cin % 32) ? 0 : conv_packed_bytes(Cout, Cin, 1); }
+
+int tedm_conv1x1_pack(const float* w, int Cout, int Cin, void* wpk, int prec, void* stream) {
+    g_err[0] = 0;
+    if (!w || !wpk || Cout % 16 || Cin % 32) return fail(TEDM_EINVAL, "conv1x1 pack: Cout %% 16 and Cin %% 32 required (got %d, %d)", Cout, Cin);
+    const int rc = pack_conv_weights(w, Cout, Cin, 1, 1, wpk, prec == TEDM_PREC_FP16X2, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "conv1x1 pack failed");
+}
+
+int tedm_conv1x1_nhwc(const float* x, int B, int H, int W, int Cin, const void* wpk, int Cout, const float* bias, const float* add,
+                      float* out, int prec, void* stream) {
+    g_err[0] = 0;
+    if (!x || !wpk || !out || Cout % 16 || Cin % 32) return fail(TEDM_EINVAL, "conv1x1: bad argument");
+    ConvArgs a{};
+    a.x1 = x; a.C1 = Cin; a.B = B; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Cout; a.wpk = wpk; a.bias = bias;
+    a.out = out; a.add = add; a.prec = prec;
+    const int rc = conv_launch(a, 1, 1, 0, PRO_NONE, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "conv1x1 launch failed (%d)", rc);
+}
+
+size_t tedm_conv1x1_wgrad_workspace_bytes(int Cout, int Cin, int B, int H, int W) {
+    return wgrad_partial_floats(1, 1, Cout, Cin, B, H, W) * 4 + 256;
+}
+
+int tedm_conv1x1_wgrad_nhwc(const float* dy, const float* x, int B, int H, int W, int Cin, int Cout, float* dw, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    if (!dy || !x || !dw || !workspace) return fail(TEDM_EINVAL, "null argument");
+    if (workspace_bytes < tedm_conv1x1_wgrad_workspace_bytes(Cout, Cin, B, H, W)) return fail(TEDM_ENOMEM, "wgrad workspace too small");
+    float* part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const int rc = op_conv_wgrad(dy, Cout, x, Cin, nullptr, 0, B, H, W, H, W, 1, 1, 0, PRO_NONE, nullptr, nullptr, part, dw, accumulate,
+                                 (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "conv1x1 wgrad failed (%d)", rc);
+}
+
+int tedm_upsample_sum_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C, const float* bias, float* out,
+                           void* stream) {
+    g_err[0] = 0;
+    if (!z || !h || !w || !out) return fail(TEDM_EINVAL, "null argument");
+    const int rc = op_upsample_sum(z, h, w, n, B, S, C, bias, out, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "upsample_sum failed (%d)", rc);
+}
+
+int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, float* out, void* stream) {
+    g_err[0] = 0;
+    if (!g || !out) return fail(TEDM_EINVAL, "null argument");
+    const int rc = op_pool_sum(g, out, B, h, w, factor, C, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "pool_sum failed (%d)", rc);
+}
+
 int tedm_unet_trace_count(const tedm_unet* h) { return h ? (int)h->trace.size() : 0; }
 const char* tedm_unet_trace_name(const tedm_unet* h, int i) {
     return (h && i >= 0 && i < (int)h->trace.size()) ? h->trace[i].name.c_str() : nullptr;

@@ -38,6 +38,7 @@ class DatasetDM(nn.Module):
         self.max_images_per_forward = int(getattr(args, 'max_images_per_forward', 64))
         feat_ch = sum(s[3] for s in self.diffusion_model.model._tap_shapes(1, 8, 8))   # 960 for the default UNet
         self.feature_channels = feat_ch
+        self.fused_head = bool(getattr(args, 'fused_head', True))
         self.classifier = nn.Sequential(                                       # datasetDM_model.py:57-64
             nn.Conv2d(feat_ch * len(self.steps), 128, 1), nn.ReLU(), nn.BatchNorm2d(128),
             nn.Conv2d(128, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
@@ -80,6 +81,38 @@ class DatasetDM(nn.Module):
                         c_off += Cc
         return feats
 
-    def forward(self, x: Tensor) -> Tensor:
-        """datasetDM_model.py:85-88."""
-        return self.classifier(self.extract_features(x).to(x.device))
+    @torch.no_grad()
+    def _taps_per_step(self, x_0: Tensor, noise: Optional[Tensor] = None):
+        """The decoder taps of every timestep in `self.steps` (what extract_features resizes and concatenates),
+        kept at their native resolution: list over t of 4 NCHW-shaped views of NHWC buffers."""
+        dm, unet = self.diffusion_model, self.diffusion_model.model
+        B = x_0.shape[0]
+        dev = x_0.device
+        per_call = max(1, self.max_images_per_forward // B) if B <= self.max_images_per_forward else 1
+        out = []
+        for s0 in range(0, len(self.steps), per_call):
+            steps = self.steps[s0:s0 + per_call]
+            xs, ts = [], []
+            for st in steps:
+                t = torch.full((B,), int(st), dtype=torch.long, device=dev)
+                x_t, _ = dm.forward_diffusion_model(x_0=x_0, t=t, noise=noise)
+                xs.append(x_t)
+                ts.append(t)
+            _, taps = unet.native_forward(torch.cat(xs, 0), torch.cat(ts, 0), taps_only=True)
+            for j in range(len(steps)):
+                out.append([tp[j * B:(j + 1) * B] for tp in taps])
+        return out
+
+    def forward(self, x: Tensor, noise: Optional[Tensor] = None) -> Tensor:
+        """datasetDM_model.py:85-88.  With `fused_head` (default) the first classifier layer runs at the taps' native
+        resolution (tedm_amd/head.py) and the (B, 960*T, S, S) feature tensor is never built; the result equals
+        `classifier(extract_features(x))` up to fp32 summation order.  `noise` pins the q-sample noise (tests)."""
+        conv = self.classifier[0]
+        fused = (self.fused_head and isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.out_channels % 16 == 0
+                 and conv.in_channels == self.feature_channels * len(self.steps))
+        if not fused:
+            return self.classifier(self.extract_features(x, noise=noise).to(x.device))
+        from .head import fused_first_layer
+        taps = self._taps_per_step(x, noise)
+        h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[self.diffusion_model.model.precision])
+        return self.classifier[1:](h1)
