@@ -204,18 +204,18 @@ static void wgrad_geometry(int k, int stride, int Cout, int Cin, int B, int Ho, 
 }
 
 // tedm_set_tuning("wgrad_mfma", v): 0 = exact-fp32 MFMA kernel everywhere, 1 = bf16x3 matrix-core path for 3x3 (default;
-// 1x1 weight gradients are staging-bound and cheaper without the planar pre-pass), 2 = bf16x3 path for 3x3 and 1x1
+// 1x1 weight gradients are staging-bound and measured cheaper without the planar pre-pass)
 static int g_wgrad_mfma = 1;
 int wgrad_set_tuning(const char* key, int v) {
-    if (!strcmp(key, "wgrad_mfma") && v >= 0 && v <= 2) { g_wgrad_mfma = v; return TEDM_OK; }
-    return TEDM_EINVAL;
+    if (!strcmp(key, "wgrad_mfma") && (v == 0 || v == 1)) { g_wgrad_mfma = v; return TEDM_OK; }
+    return wgrad_mfma_set_tuning(key, v);
 }
 
 size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo) {
     int TR, tx, ty, S, tpw;
     wgrad_geometry(k, stride, Cout, Cin, B, Ho, Wo, &TR, &tx, &ty, &S, &tpw);
     size_t n = (size_t)S * k * k * Cout * Cin;
-    if (stride == 1 && (k == 1 || k == 3)) {                       // sized for either path (the switch is a runtime tuning key)
+    if (stride == 1 && k == 3) {                                   // sized for either path (the switch is a runtime tuning key)
         const size_t m = wgrad_mfma_floats(k, Cout, Cin, B, Ho, Wo);
         if (m > n) n = m;
     }
@@ -231,7 +231,7 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     WgradArgs a{};
     a.dy = dy; a.Cout = Cout; a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.pro_a = pro_a; a.pro_b = pro_b; a.part = part;
-    if (stride == 1 && ((k == 3 && g_wgrad_mfma >= 1) || (k == 1 && g_wgrad_mfma == 2))) {
+    if (stride == 1 && k == 3 && g_wgrad_mfma && (pro == PRO_NONE || pro == PRO_GN)) {
         int S = 0;
         const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, st);
         if (rc != TEDM_OK) return rc;
