@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_kernel(WgArgs a) {
     do {                                                                                                           \
         const int n_ = (TL) / tpi;                                                                                 \
         const int trem_ = (TL) - n_ * tpi;                                                                         \
-        const int ty_ = trem_ / a.tiles_x, tx_ = trem_ - ty_ * a.tiles_x;                                          \
+        const int tx_ = trem_ / a.tiles_y, ty_ = trem_ - tx_ * a.tiles_y;   /* rows fastest: consecutive tiles share 2 of 4 halo rows (L2) */ \
         const size_t odyt = ((size_t)(n_ * a.Hp + ty_ * TR) * a.tiles_x + tx_) * a.Cout * 32;                     \
         const size_t oxt = ((size_t)(n_ * a.Hp + ty_ * TR) * a.tiles_x + tx_) * a.Cin * 40;                       \
         const uint16_t *bdyh = a.dyh + odyt, *bdyl = a.dyl + odyt, *bxh = a.xh + oxt, *bxl = a.xl + oxt;           \
