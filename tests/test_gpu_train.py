@@ -36,16 +36,19 @@ def oracle_grads(m, x, t, R, dim):
     return eps.detach(), {k: v.grad for k, v in p.items() if v.grad is not None}
 
 
-@pytest.mark.parametrize('dim,S,B,use_t', [(32, 32, 2, True), (32, 16, 3, False), (64, 64, 2, True)])
+@pytest.mark.parametrize('dim,S,B,use_t', [(32, 32, 2, True), (32, 16, 3, False), (64, 64, 2, True), (32, (24, 40), 1, True)])
 def test_param_grads_vs_oracle_autograd(dev, dim, S, B, use_t):
+    """S = (H, W) covers a non-square image whose width is not a multiple of the 32-pixel tiles (ragged column tile,
+    zero-filled plane tails) and a single-image batch."""
+    H, W = S if isinstance(S, tuple) else (S, S)
     from tedm_amd import Unet, load_synth_weights
     m = Unet(dim)
     load_synth_weights(m, seed=3)
     m = m.to(dev).train()
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, 1, S, S, generator=g)
+    x = torch.randn(B, 1, H, W, generator=g)
     t = torch.randint(0, 1000, (B,), generator=g) if use_t else None
-    R = torch.randn(B, 1, S, S, generator=g)
+    R = torch.randn(B, 1, H, W, generator=g)
     eps_ref, gref = oracle_grads(m, x, t, R, dim)
     eps = m(x.to(dev), t.to(dev) if use_t else None)
     assert eps.requires_grad
