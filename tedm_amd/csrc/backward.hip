@@ -67,7 +67,7 @@ __global__ void pool_sum_kernel(const float* __restrict__ g, float* __restrict__
 }
 
 TEDM_DEVFN float dsilu_f(float u) {            // d/du [u * sigmoid(u)]
-    const float sg = 1.0f / (1.0f + __expf(-u));
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
     return sg * (1.0f + u * (1.0f - sg));
 }
 
