@@ -271,6 +271,9 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     const int cstride = a.Cout;
     auto epilogue = [&](int tl) {
         if (!active) return;
+#ifdef TEDM_DIAG_TRACE
+        if (a.prio_mode == 3) return;                          // diagnostic: what the tile costs without its epilogue
+#endif
         const int n = tl / tpi;
         const int trem = tl - n * tpi;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
@@ -279,13 +282,18 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
         if (a.add_a && cok) { aa = a.add_a[(size_t)n * a.Cout + cout]; ab = a.add_b[(size_t)n * a.Cout + cout]; }
         float s1 = 0.f, s2 = 0.f, smax = -INFINITY;
         const bool full_cols = ox0 + 32 <= a.Wo;               // block-uniform
-        auto emit = [&](auto mode) {
+        // Addresses are (uniform row pointer + uniform pixel step) + a 32-bit per-lane offset, so a store is one
+        // instruction with a scalar base and no per-lane 64-bit arithmetic; the statistics are only accumulated when a
+        // slab was asked for.  (The epilogue is 15 % of a 64-channel conv's workgroup time: every VALU slot counts.)
+        const unsigned lane_off = (unsigned)(4 * h * cstride + cout);
+        auto emit = [&](auto mode, auto with_stats) {
             constexpr int MODE = decltype(mode)::value;       // 0: no addend, 1: plain addend, 2: silu(aa*add+ab)
+            constexpr bool ST = decltype(with_stats)::value;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int oy = oy0 + wm * MT + mt;
                 if (oy >= a.Ho) continue;                      // wave-uniform
-                const size_t rowbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox0 + 4 * h) * cstride + cout;
+                const size_t rowbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox0) * cstride;      // uniform
                 float* op = a.out + rowbase;
                 const float* ap = MODE ? a.add + rowbase : nullptr;
                 if (full_cols) {
@@ -293,15 +301,15 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
                     float ad[16];
                     if (MODE) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) ad[i] = ap[((i & 3) + 8 * (i >> 2)) * cstride];
+                        for (int i = 0; i < 16; ++i) ad[i] = (ap + (size_t)((i & 3) + 8 * (i >> 2)) * cstride)[lane_off];
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         float v = acc[mt][i] + bias;
                         if (MODE == 1) v += ad[i];
                         if (MODE == 2) v += silu_f(fmaf(aa, ad[i], ab));
-                        op[((i & 3) + 8 * (i >> 2)) * cstride] = v;
-                        s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                        (op + (size_t)((i & 3) + 8 * (i >> 2)) * cstride)[lane_off] = v;
+                        if (ST) { s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v); }
                     }
                 } else {
 #pragma unroll
@@ -310,20 +318,21 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
                         if (ox0 + 4 * h + dx < a.Wo && cok) {
                             float v = acc[mt][i] + bias;
                             if (MODE) {
-                                float t = ap[dx * cstride];
+                                float t = (ap + (size_t)dx * cstride)[lane_off];
                                 if (MODE == 2) t = silu_f(fmaf(aa, t, ab));
                                 v += t;
                             }
-                            op[dx * cstride] = v;
-                            s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v);
+                            (op + (size_t)dx * cstride)[lane_off] = v;
+                            if (ST) { s1 += v; s2 = fmaf(v, v, s2); smax = fmaxf(smax, v); }
                         }
                     }
                 }
             }
         };
-        if (!a.add) emit(std::integral_constant<int, 0>{});
-        else if (!a.add_a) emit(std::integral_constant<int, 1>{});
-        else emit(std::integral_constant<int, 2>{});
+        const bool st_on = a.stats_mode != STATS_NONE;
+        if (!a.add) { if (st_on) emit(std::integral_constant<int, 0>{}, std::true_type{}); else emit(std::integral_constant<int, 0>{}, std::false_type{}); }
+        else if (!a.add_a) emit(std::integral_constant<int, 1>{}, std::false_type{});      // addend and statistics never meet on this path
+        else emit(std::integral_constant<int, 2>{}, std::false_type{});
 
         if (a.stats_mode != STATS_NONE) {
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); smax = fmaxf(smax, __shfl_xor(smax, 32));
@@ -503,7 +512,7 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
-    if (!strcmp(key, "conv_prio") && v >= 0 && v <= 2) { g_prio_mode = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_prio") && v >= 0 && v <= 3) { g_prio_mode = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }

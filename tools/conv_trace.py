@@ -20,6 +20,8 @@ def main():
     os.environ['TEDM_TRACE_FILE'] = tf
     from tedm_amd import _lib
     L = _lib.lib()
+    if os.environ.get('CONV_PRIO'):
+        _lib.check(L.tedm_set_tuning(b'conv_prio', int(os.environ['CONV_PRIO'])))
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, S, S, cin, generator=g).to(dev)
