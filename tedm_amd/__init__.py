@@ -4,6 +4,9 @@ Host side (this package): nn.Module facades with the reference's surface
 (models/unet_model.py `Unet`, models/diffusion_model.py `DiffusionModel`,
 models/datasetDM_model.py `DatasetDM`).  Compute: hand-written HIP kernels for gfx950 in
 tedm_amd/csrc behind the C ABI of include/tedm_hip.h (libtedm_hip.so, loaded with ctypes).
+
+Also here: `trainer` (the reference training loop / checkpoint format over the native train step), `dp` (one process per
+GPU: sharding, flat-gradient all-reduce), `head` (pixel-classifier first layer fused into the decoder taps).
 """
 from .unet import Unet                      # noqa: F401
 from .diffusion import DiffusionModel       # noqa: F401

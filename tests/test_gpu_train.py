@@ -152,3 +152,24 @@ def test_native_train_step_matches_autograd_path(dev):
     assert abs(float(loss2) - float(loss)) < 1e-6 * abs(float(loss))
     for k, p in dm.model.named_parameters():
         assert torch.equal(p.grad, ref[k]), k
+
+
+def test_two_channel_joint_model_forward_and_grads(dev):
+    """`--experiment joint` trains on image+mask as a 2-channel input (trainers/train_base_diffusion.py:25-26,
+    models/diffusion_model.py:69-73 with channels=2): stem / final conv with Cin, out_dim = 2."""
+    from oracle import unet_ref as O
+    from tedm_amd import Unet, load_synth_weights
+    m = Unet(32, channels=2)
+    load_synth_weights(m, seed=8)
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    x, t, R = torch.randn(2, 2, 16, 16, generator=g), torch.tensor([5, 700]), torch.randn(2, 2, 16, 16, generator=g)
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    with torch.enable_grad():
+        eps_ref = O.unet_forward(p, x, t, dim=32)
+        (eps_ref * R).sum().backward()
+    eps = m(x.to(dev), t.to(dev))
+    assert rel(eps.detach(), eps_ref.detach()) < 1e-4
+    eps.backward(R.to(dev))
+    for k in ('init_conv.weight', 'init_conv.bias', 'final_conv.weight', 'final_conv.bias', 'downs.0.0.block1.proj.weight'):
+        assert rel(m.get_parameter(k).grad, p[k].grad) < GRAD_TOL, k
