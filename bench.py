@@ -211,9 +211,11 @@ def main() -> None:
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run', file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    dist = dp.init('nccl') if world > 1 else None
+    # TEDM_DIST_BACKEND=gloo + fewer GPUs than ranks = rehearsal of the multi-process path on a one-GPU box (ranks share the card)
+    backend = os.environ.get('TEDM_DIST_BACKEND', 'nccl')
+    dist = dp.init(backend) if world > 1 else None
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the HIP path has no CPU fallback)'
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     L = _lib.lib()
     if args.tile_wide is not None:

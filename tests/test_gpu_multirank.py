@@ -1,0 +1,37 @@
+"""GPU (one MI355X): rehearsal of the one-process-per-GPU launch that the driver runs at N = 2, 4, 8 -- two ranks started by
+torch.distributed.run share the single card (TEDM_DIST_BACKEND=gloo: RCCL refuses two ranks on one device), exercising
+bench.py's rank plumbing, the barrier / max-over-ranks timing and, in train mode, the flat-gradient all-reduce."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(port, *extra):
+    env = dict(os.environ, TEDM_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--size', '64', '--no-cpu-baseline', *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_denoise_line(built_lib):
+    d = run_bench(29541)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['unit'] == 'img/s' and d['vs_baseline'] is None
+    assert d['value'] > 0 and abs(d['value'] - 2 * 2 * d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) < 1e-2 * d['value']
+    assert 'roofline' in d and 'cpu_baseline' not in d      # the CPU baseline is an N = 1 leg
+
+
+def test_two_ranks_train_line(built_lib):
+    d = run_bench(29542, '--mode', 'train')
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['final_loss'] > 0
