@@ -439,6 +439,7 @@ struct TileSel { int wm, wn, mt; };
 int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
 int g_tile_narrow = 1;
 int g_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
+int g_solo = 0;           // tedm_set_tuning("conv_solo", 1): pad the LDS request so that workgroups do not share a CU (diagnostic)
 int g_tpw_max = 1;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
 int g_xcd_order = 1;      // 1: cout-tile groups of one input tile share an XCD (tedm_set_tuning("conv_xcd_order", v))    // tile id used when Cout <  128 (tedm_set_tuning("conv_tile_narrow", v))
 
@@ -462,7 +463,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     auto kern = conv_igemm_kernel<KH, KW, STRIDE, PAD, UPS, WM, WN, MT, KS, NBUF, PRO, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return TEDM_EHIP;
         attr_set = true;
     }
@@ -478,7 +479,8 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     b.tpw = tpw;
     b.prio_mode = g_prio_mode;
     dim3 grid(((ntile + tpw - 1) / tpw) * b.ny);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), G::LDS, st, b);
+    const size_t lds = g_solo ? (size_t)(96 * 1024 > G::LDS ? 96 * 1024 : G::LDS) : (size_t)G::LDS;   // conv_solo: one workgroup per CU (diagnostic)
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, b);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
 
@@ -513,6 +515,7 @@ int launch_prec(const ConvArgs& a, int KH, int stride, int ups, int pro, int til
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
     if (!strcmp(key, "conv_prio") && v >= 0 && v <= 3) { g_prio_mode = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_solo") && (v == 0 || v == 1)) { g_solo = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }

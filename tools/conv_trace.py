@@ -20,6 +20,8 @@ def main():
     os.environ['TEDM_TRACE_FILE'] = tf
     from tedm_amd import _lib
     L = _lib.lib()
+    if os.environ.get('CONV_SOLO'):
+        _lib.check(L.tedm_set_tuning(b'conv_solo', int(os.environ['CONV_SOLO'])))
     if os.environ.get('CONV_PRIO'):
         _lib.check(L.tedm_set_tuning(b'conv_prio', int(os.environ['CONV_PRIO'])))
     dev = torch.device('cuda:0')
