@@ -329,6 +329,10 @@ struct Fwd {
         if (g_prof.level >= 1) {
             char label[160];
             conv_kernel_label(a, w.k, stride, ups, pro, label, sizeof(label));
+            if (g_prof.level >= 3) {                       // level 3: one entry per layer shape
+                const size_t n = strlen(label);
+                snprintf(label + n, sizeof(label) - n, " %d->%d @%dx%d", C1 + C2, w.cout, Ho, Wo);
+            }
             const double cin = C1 + C2;
             g_prof.begin(label, 2.0 * B * Ho * Wo * w.cout * cin * w.k * w.k,
                          4.0 * B * ((double)H * W * cin + (double)Ho * Wo * w.cout * (add ? 2 : 1)), st);
