@@ -193,7 +193,7 @@ def main():
     np.savez(GOLD / 'classifier_d64_s16.npz', x0=x0.numpy(), noise=noise.numpy(), steps=np.array([50, 150, 250]),
              feats_mean=f_ref.mean(dim=(2, 3)).numpy(), logits=logits.numpy())
 
-    # ---- 4. three Adam steps of DiffusionModel.train_step (config 1 plumbing; backward = later round)
+    # ---- 4. three Adam steps of DiffusionModel.train_step (config 1: pins the native backward + Adam trace, tests/test_gpu_train.py)
     torch.set_grad_enabled(True)
     dm_tr = RDiff(cfg_ns(64))
     dm_tr.model.load_state_dict(w64)

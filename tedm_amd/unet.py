@@ -12,6 +12,10 @@ What is kept from the reference surface:
 
 The sub-modules are parameter containers: the arithmetic of the whole forward is one call into the
 native library (no per-layer PyTorch ops, no CPU fallback).  Calling a sub-module on its own raises.
+
+Training: with autograd enabled and parameters requiring grad, `forward` goes through `_UnetTrainFn`
+(`tedm_unet_forward_train` records a tape in a workspace, `tedm_unet_backward` writes all parameter gradients into
+`grad_flat`); `native_forward_train` / `native_backward` are the same two calls without autograd.
 """
 from __future__ import annotations
 

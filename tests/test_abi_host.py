@@ -119,3 +119,26 @@ def test_checkpoint_roundtrip(tmp_path):
     dm2 = DiffusionModel(ck['config'])
     dm2.load_state_dict(ck['model_state_dict'])
     assert all(torch.equal(a, b) for a, b in zip(dm.state_dict().values(), dm2.state_dict().values()))
+
+
+def test_workspace_sizing_is_host_only_and_monotonic(built_lib):
+    """tedm_unet_workspace_bytes / tedm_unet_train_workspace_bytes are dry runs of the launch sequence (no device)."""
+    from tedm_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.UnetCfg()
+    cfg.dim, cfg.n_mults, cfg.channels, cfg.groups, cfg.heads, cfg.dim_head = 64, 4, 1, 8, 4, 32
+    for i, v in enumerate((1, 2, 4, 8)):
+        cfg.dim_mults[i] = v
+    h = C.c_void_p()
+    _lib.check(L.tedm_unet_create(C.byref(cfg), C.byref(h)))
+    f1, f2 = L.tedm_unet_workspace_bytes(h, 2, 64, 64, 0), L.tedm_unet_workspace_bytes(h, 4, 64, 64, 0)
+    t1, t2 = L.tedm_unet_train_workspace_bytes(h, 2, 64, 64), L.tedm_unet_train_workspace_bytes(h, 4, 64, 64)
+    assert 0 < f1 < f2 and 0 < t1 < t2 and t1 > f1              # the tape keeps what the inference arena recycles
+    assert L.tedm_unet_workspace_bytes(h, 2, 60, 64, 0) == 0    # H must be a multiple of 8
+    assert L.tedm_unet_train_workspace_bytes(h, 0, 64, 64) == 0
+    # training entry points refuse to run before parameters / gradients are bound and packed
+    assert L.tedm_unet_forward_train(h, C.c_void_p(8), None, 2, 64, 64, C.c_void_p(8), C.c_void_p(8), 1 << 20, None, 0) != 0
+    assert b'pack' in L.tedm_last_error()
+    assert L.tedm_unet_backward(h, C.c_void_p(8), C.c_void_p(8), 1 << 20, None) != 0
+    assert b'tape' in L.tedm_last_error()
+    L.tedm_unet_destroy(h)
