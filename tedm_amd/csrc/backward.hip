@@ -574,7 +574,13 @@ inline bool pixmap(int C, PixMap& m) {
         default: hipLaunchKernelGGL(KERN<4>, __VA_ARGS__); break;                              \
     }
 
-int gn_bwd_chunks(long long hw) { long long e = hw / 1024; return (int)(e < 1 ? 1 : e); }
+// pixel chunks per image of the reduction pass: 1024-pixel chunks at the large levels, but never fewer than 16 per image
+// (>= 32 pixels each) so that the 32x32 / 64x64 levels still put ~500 workgroups on the chip
+int gn_bwd_chunks(long long hw) {
+    long long e = hw / 1024, lo = hw / 32 < 16 ? hw / 32 : 16;
+    if (e < lo) e = lo;
+    return (int)(e < 1 ? 1 : e);
+}
 
 // GroupNorm(+FiLM)+SiLU backward.  Workspace (floats): slab B*E*C*3, ca B*C, mcoef B*groups*2, dgam_n/dbet_n/dbias_n B*C each.
 int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
