@@ -514,6 +514,87 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         }
     }
 }
+// Matrix-core version (Cout <= 64, Cin*49 <= 128): the same sum as a GEMM on the exact-fp32 MFMA with
+// i = output channel, j = (ci,ky,kx) tap and k = pixel parity; each lane gathers ITS tap's shifted pixel from the haloed
+// LDS tile.  Every wave owns 2 rows of the 8x32 tile and writes its own partial slice [K][Cout] (4 slices per workgroup).
+template <int NCB, int NTB>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ dY, const float* __restrict__ x, int B, int Cin,
+                                                              int H, int W, int Cout, int tpb, float* __restrict__ part) {
+    constexpr int TR = 8, TC = 32, HR = TR + 6, HC = TC + 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sdy = (float*)smem;                       // [256][64]
+    float* sx = sdy + 256 * 64;                      // [Cin][HR][HC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tpi = tiles_x * tiles_y, ntile = B * tpi;
+    const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntile) ? t_beg + tpb : ntile;
+    const int K = Cin * 49;
+    int boff[NTB];                                   // LDS offset of this lane's tap inside the halo tile, -1 = no such tap
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+        const int tt = nb * 32 + li;
+        const int ci = tt / 49, tap = tt - ci * 49, ky = tap / 7, kx = tap - ky * 7;
+        boff[nb] = tt < K ? (ci * HR + ky) * HC + kx : -1;
+    }
+    f32x16 acc[NCB][NTB];
+#pragma unroll
+    for (int a_ = 0; a_ < NCB; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < NTB; ++b_)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a_][b_][i] = 0.f;
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        const int n = tl / tpi, trem = tl - n * tpi, ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * TR, ox0 = tx * TC;
+        __syncthreads();
+        for (int i = tid; i < 256 * 16; i += 256) {
+            const int px = i >> 4, c4 = (i & 15) * 4;
+            const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+            const bool ok = oy < H && ox < W && c4 < Cout;
+            const int oyc = oy < H ? oy : H - 1, oxc = ox < W ? ox : W - 1, cc = c4 < Cout ? c4 : 0;
+            float4 v = *(const float4*)(dY + ((size_t)(n * H + oyc) * W + oxc) * Cout + cc);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4*)(sdy + px * 64 + c4) = v;
+        }
+        for (int i = tid; i < Cin * HR * HC; i += 256) {
+            const int ci = i / (HR * HC), rem = i - ci * HR * HC, hy = rem / HC, hx = rem - hy * HC;
+            const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];
+            sx[i] = ok ? v : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+            const int py = 2 * wave + (q >> 4), pxx = 2 * (q & 15) + lk;          // this lane's pixel of the pair (k = parity)
+            float av[NCB], bv[NTB];
+#pragma unroll
+            for (int a_ = 0; a_ < NCB; ++a_) av[a_] = sdy[(py * 32 + pxx) * 64 + a_ * 32 + li];
+#pragma unroll
+            for (int b_ = 0; b_ < NTB; ++b_) {
+                const int o = boff[b_] < 0 ? 0 : boff[b_];
+                const float t = sx[o + py * HC + pxx];
+                bv[b_] = boff[b_] < 0 ? 0.f : t;
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < NCB; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < NTB; ++b_) acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a_], bv[b_], acc[a_][b_], 0, 0, 0);
+        }
+    }
+    // partial slice of this wave: part[(block*4 + wave)][k][co]; acc reg s of lane l = (co row (s&3)+8(s>>2)+4(l>>5), tap l&31)
+    float* out = part + ((size_t)blockIdx.x * 4 + wave) * K * Cout;
+#pragma unroll
+    for (int a_ = 0; a_ < NCB; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < NTB; ++b_)
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int co = a_ * 32 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk, k = b_ * 32 + li;
+                if (co < Cout && k < K) out[(size_t)k * Cout + co] = acc[a_][b_][s_];
+            }
+}
 // dW[co][k] (+)= sum_blocks part[block][k][co]
 __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nb, int K, int Cout, float* __restrict__ dW, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -679,27 +760,42 @@ int op_final_conv_backward(const float* dY_nchw, const float* x, const float* w,
     }
     return LAUNCH_OK();
 }
+// number of partial slices [Cin*49][Cout] the stem weight gradient writes (4 per workgroup: one per wave)
 int stem_wgrad_blocks(int B, int H, int W) {
     const long long ntile = (long long)B * ((W + 31) / 32) * ((H + 7) / 8);
     long long nb = ntile / 16;
-    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    return (int)(nb * 4);
 }
 // part: stem_wgrad_blocks*Cin*49*Cout floats
 int op_stem_wgrad(const float* dY, const float* x_nchw, int B, int Cin, int H, int W, int Cout, float* part, float* dW,
                   int accumulate, hipStream_t st) {
-    const int nb = stem_wgrad_blocks(B, H, W);
+    const int nb = stem_wgrad_blocks(B, H, W) / 4;
     const long long ntile = (long long)B * ((W + 31) / 32) * ((H + 7) / 8);
     const int tpb = (int)((ntile + nb - 1) / nb);
     const size_t lds = (size_t)(256 * 64 + Cin * 14 * 38) * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TEDM_EHIP;
-        attr = true;
-    }
     const int nb2 = (int)((ntile + tpb - 1) / tpb);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb2), dim3(256), lds, st, dY, x_nchw, B, Cin, H, W, Cout, tpb, part);
     const int K = Cin * 49;
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((K * Cout + 255) / 256), dim3(256), 0, st, part, nb2, K, Cout, dW, accumulate);
+    int slices = nb2;
+    auto set_attr = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    if (Cout <= 64 && Cout % 4 == 0 && K <= 128) {                 // matrix-core path
+        const int ncb = (Cout + 31) / 32, ntb = (K + 31) / 32;
+#define STEM_CASE(A, Bk)                                                                                              \
+        if (ncb == A && ntb == Bk) {                                                                                  \
+            static bool attr = false;                                                                                 \
+            if (!attr) { if (!set_attr((const void*)stem_wgrad_mfma_kernel<A, Bk>)) return TEDM_EHIP; attr = true; }   \
+            hipLaunchKernelGGL((stem_wgrad_mfma_kernel<A, Bk>), dim3(nb2), dim3(256), lds, st, dY, x_nchw, B, Cin, H, W, Cout, tpb, part); \
+        }
+        STEM_CASE(1, 2) STEM_CASE(2, 2) STEM_CASE(1, 4) STEM_CASE(2, 4)
+#undef STEM_CASE
+        if (!((ncb == 1 || ncb == 2) && (ntb == 2 || ntb == 4))) return TEDM_EINVAL;
+        slices = nb2 * 4;
+    } else {
+        static bool attr = false;
+        if (!attr) { if (!set_attr((const void*)stem_wgrad_kernel)) return TEDM_EHIP; attr = true; }
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb2), dim3(256), lds, st, dY, x_nchw, B, Cin, H, W, Cout, tpb, part);
+    }
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((K * Cout + 255) / 256), dim3(256), 0, st, part, slices, K, Cout, dW, accumulate);
     return LAUNCH_OK();
 }
 // part: B*64 floats
