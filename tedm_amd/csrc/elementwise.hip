@@ -99,6 +99,80 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     }
 }
 
+// Matrix-core stem (Cin*49 <= 128 taps, Cout in {32, 64}): out[pixel][co] = sum_tap x[pixel + tap] * w[co][tap] as a GEMM on
+// the exact-fp32 MFMA with i = pixel (one 32-pixel row segment per M tile), j = output channel, k = tap parity: every lane
+// gathers its pixel's sample for its tap from the haloed LDS tile.  One wave = 2 rows x all output channels.
+template <int NCB>
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int Cin, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = Cin * 49, K2 = (K + 1) / 2;
+    float* sx = (float*)smem;                               // [Cin][HR][HC]
+    float* sw = sx + ((Cin * STEM_HR * STEM_HC + 3) & ~3);  // [2*K2][Cout]  (row K zero when K is odd)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
+    int tile = blockIdx.x;
+    const int n = tile / (tiles_x * tiles_y);
+    tile -= n * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * STEM_TR, ox0 = tx * STEM_TC;
+    for (int i = tid; i < Cin * STEM_HR * STEM_HC; i += 256) {
+        const int ci = i / (STEM_HR * STEM_HC);
+        const int rem = i - ci * STEM_HR * STEM_HC;
+        const int hy = rem / STEM_HC, hx = rem - hy * STEM_HC;
+        const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];          // unconditional load, clamped address
+        sx[i] = ok ? v : 0.f;
+    }
+    for (int i = tid; i < 2 * K2 * Cout; i += 256) {
+        const int k = i / Cout, co = i - k * Cout;
+        const float v = w[(size_t)co * K + (k < K ? k : 0)];
+        sw[i] = k < K ? v : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[2][NCB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+    for (int kk = 0; kk < K2; ++kk) {
+        const int t = 2 * kk + lk;
+        const int tc = t < K ? t : 0;
+        const int ci = tc / 49, tap = tc - ci * 49, ky = tap / 7, kx = tap - ky * 7;
+        const float* ax = sx + (ci * STEM_HR + 2 * wave + ky) * STEM_HC + li + kx;
+        float a0 = ax[0], a1 = ax[STEM_HC];
+        if (t >= K) { a0 = 0.f; a1 = 0.f; }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const float bv = sw[t * Cout + c * 32 + li];
+            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int oy = oy0 + 2 * wave + m;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int co = c * 32 + li;
+            const float bs = bias[co];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int ox = ox0 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk;
+                if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = acc[m][c][s_] + bs;
+            }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------
 // time MLP: SinusoidalPosEmb -> Linear -> GELU(erf) -> Linear (models/unet_model.py:76-93,287-292)
 // followed by the SiLU every ResnetBlock.time_mlp applies first (:149-152).  One block per sample.
@@ -495,6 +569,14 @@ int op_q_sample(const float* x0, const float* noise, const long long* t, const f
 
 int op_stem_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                  int Cout, hipStream_t st) {
+    const int tiles = ((W + STEM_TC - 1) / STEM_TC) * ((H + STEM_TR - 1) / STEM_TR);
+    const int K = Cin * 49;
+    if (K <= 128 && (Cout == 32 || Cout == 64)) {                 // matrix-core path
+        const size_t lds = (size_t)((Cin * STEM_HR * STEM_HC + 3) & ~3) * 4 + (size_t)2 * ((K + 1) / 2) * Cout * 4;
+        if (Cout == 32) hipLaunchKernelGGL(stem_conv_mfma_kernel<1>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        else hipLaunchKernelGGL(stem_conv_mfma_kernel<2>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        return LAUNCH_OK();
+    }
     const size_t lds = (size_t)((Cin * STEM_HR * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 49 * 64 * 4;
     if (lds > 160 * 1024) return TEDM_EINVAL;
     static bool attr = false;
@@ -503,7 +585,6 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
             return TEDM_EHIP;
         attr = true;
     }
-    const int tiles = ((W + STEM_TC - 1) / STEM_TC) * ((H + STEM_TR - 1) / STEM_TR);
     hipLaunchKernelGGL(stem_conv_kernel, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
     return LAUNCH_OK();
 }
