@@ -173,3 +173,29 @@ def test_two_channel_joint_model_forward_and_grads(dev):
     eps.backward(R.to(dev))
     for k in ('init_conv.weight', 'init_conv.bias', 'final_conv.weight', 'final_conv.bias', 'downs.0.0.block1.proj.weight'):
         assert rel(m.get_parameter(k).grad, p[k].grad) < GRAD_TOL, k
+
+
+def test_trainer_loop_native_path_checkpoint_and_resume(dev, tmp_path):
+    """tedm_amd.trainer.train on the GPU (train_step_native + Adam), best-validation checkpoint, resume from it."""
+    from tedm_amd import DiffusionModel, trainer
+    cfg = Namespace(normalize=True, dim=32, dim_mults=(1, 2, 4, 8), channels=1, timesteps=1000, beta_schedule='cosine',
+                    objective='pred_noise', device=str(dev), lr=1e-3, log_freq=2, val_freq=3, max_val_steps=1, max_steps=6, debug=False,
+                    log_dir=str(tmp_path / 'run'), resume_path=None)
+    torch.manual_seed(0)
+    dm = DiffusionModel(cfg).to(dev)
+    opt = torch.optim.Adam(dm.parameters(), lr=cfg.lr)
+    g = torch.Generator().manual_seed(1)
+    loader = [torch.rand(4, 1, 32, 32, generator=g) for _ in range(2)]
+    w0 = dm.model.init_conv.weight.detach().clone()
+    losses = []
+    trainer.train(cfg, dm, opt, loader, loader[:1], None, 0, on_step=lambda s, l: losses.append(l))
+    assert len(losses) == 6 and all(l == l and l > 0 for l in losses)
+    assert not torch.equal(w0, dm.model.init_conv.weight.detach())               # parameters moved
+    ck = tmp_path / 'run' / 'best_model.pt'
+    assert ck.exists()
+    dm2, opt2, step = trainer.load(cfg, ck)
+    assert step in (3, 6)
+    more = []
+    cfg2 = Namespace(**{**vars(cfg), 'max_steps': step + 2})
+    trainer.train(cfg2, dm2, opt2, loader, None, None, step, on_step=lambda s, l: more.append(s))
+    assert more == [step + 1, step + 2]
