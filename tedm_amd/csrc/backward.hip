@@ -205,6 +205,28 @@ __global__ __launch_bounds__(1024) void sum_over_batch_kernel(const float* __res
     }
 }
 
+// three [R][C] -> [C] column sums in one launch (blockIdx.y selects the array): d gamma, d beta, d bias of one GroupNorm
+__global__ __launch_bounds__(1024) void sum_over_batch3_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                               const float* __restrict__ in2, int R, int C, float* __restrict__ out0,
+                                                               float* __restrict__ out1, float* __restrict__ out2, int accumulate) {
+    __shared__ double red[16][64];
+    const float* in = blockIdx.y == 0 ? in0 : (blockIdx.y == 1 ? in1 : in2);
+    float* out = blockIdx.y == 0 ? out0 : (blockIdx.y == 1 ? out1 : out2);
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int n = rl; n < R; n += 16) s += in[(size_t)n * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
+}
+
 // Pass B: dy = ca*du - M0r - xhat*M1r
 template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ y,
@@ -676,9 +698,8 @@ int op_gn_silu_backward(const float* G, const float* y, const float* fa, const f
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * groups), dim3(64), 0, st, slab, E, C, groups, hw, mr, gamma, beta, film,
                        film_stride, dfilm, ca, mcoef, dgam_n, dbet_n, dbias_n);
     const int cb = (C + 63) / 64;
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dgam_n, B, C, dgamma, accumulate);
-    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dbet_n, B, C, dbeta, accumulate);
-    if (dbias) hipLaunchKernelGGL(sum_over_batch_kernel, dim3(cb), dim3(1024), 0, st, dbias_n, B, C, dbias, accumulate);
+    hipLaunchKernelGGL(sum_over_batch3_kernel, dim3(cb, dbias ? 3 : 2), dim3(1024), 0, st, dgam_n, dbet_n, dbias_n, B, C, dgamma, dbeta,
+                       dbias, accumulate);
     const long long P = (long long)B * hw;
     long long waves = (P + (64 / m.lpp) - 1) / (64 / m.lpp), blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
