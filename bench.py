@@ -314,6 +314,10 @@ def main() -> None:
                 'kernel_share_of_step': round(ms / (1e3 * elapsed), 4),
                 'all_conv_share_of_step': round(conv_ms / (1e3 * elapsed), 4),
                 'all_conv_tflops': round(sum(e[3] for e in conv_prof) / (conv_ms * 1e-3) / 1e12, 2),
+                # `achieved` counts ALGORITHMIC flops; the parity mode issues 3 bf16 MFMA products per algorithmic product (1 for
+                # --prec bf16, 2 for fp16x2), so the matrix pipes are busy `frac * mfma_products` of the nominal peak
+                'mfma_products': {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1}[args.prec],
+                'frac_of_issued_mfma_peak': round(achieved * {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1}[args.prec] / PEAK_BF16_TFLOPS, 4),
             }
         per_img = elapsed / (B * K)
         scale = (S / 256.0) ** 2
