@@ -204,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     // Weight fragments are fetched one or two tap-column groups (all ky of one kx) AHEAD of the MFMAs that
     // consume them; the group's registers are bq[set].  Sets are indexed statically (kx, or the chunk
     // parity for 1x1) so they stay in VGPRs.
-    constexpr int NSET = KW > 1 ? KW : 2;
+    constexpr int NSET = KW == 3 ? 3 : 2;   // 4x4: two sets, one tap column ahead (four sets of 4x4 fragments = 128 VGPRs spilled)
     uint4 bq[NSET][KH][KS][NPB];
 
     // Inactive waves (cout group past the end) run the same straight-line code on the last valid group and
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
     if (NBUF == 2) {
         // weight groups are fetched PD groups ahead (two tap columns ~ 2 x 36 MFMAs of cover for the L2
         // latency); the sequence simply wraps to chunk 0 at a tile boundary (same weights, next tile)
-        constexpr int PD = KW > 1 ? 2 : 1;
+        constexpr int PD = KW == 3 ? 2 : 1;
         const int total = tile_cnt * NC;                      // flattened (tile, chunk) iterations
         // VMEM returns in order (vmcnt): the next chunk's ACTIVATION loads are issued after the last weight
         // group this chunk still has to wait for (the kx=0 prefetch of tap column PD), so no MFMA of this
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64, (MT * STRIDE >= 8 ? 1 : 2)) void conv
         };
         setup_tile(tile_beg);
         load_b(0, 0, bq[0]);
-        if (KW > 1) load_b(0, 1 % KW, bq[1 % NSET]);
+        if (PD == 2) load_b(0, 1 % KW, bq[1 % NSET]);
         issue_loads(0);
         write_lds(0);
         __syncthreads();
