@@ -5,6 +5,9 @@
 // attention output:
 //   sweep KMAX : k = Wk LN(x)            -> per-(sample, channel) max over pixels (softmax stabiliser)
 //   sweep CTX  : k, v = Wk,Wv LN(x)      -> ctx_p[d][e] = sum_n exp(k[n][d]-kmax[d]) v[n][e],  z_p[d]
+//                (kmax == NULL: ONLINE form -- no KMAX sweep; every workgroup keeps a running per-channel max m_p[d],
+//                 rescales its accumulators when it grows, and the finalize kernel merges the partials with
+//                 exp(m_p - max_p m_p), exactly like a split softmax)
 //   sweep QOUT : q = Wq LN(x)            -> o[n][e] = sum_d ctx[d][e] softmax_d(q[n])[d] * 32^-0.5
 // One wave per head; a workgroup walks TPW consecutive 128-pixel tiles of one image (1x1 convolution:
 // pixels are a flat index).  The projection runs on v_mfma_f32_32x32x16_{bf16,f16} in the handle's
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
     float kmx = 0.f;
-    if (EPI == LA_CTX) kmx = a.kmax[(size_t)n * hd * 32 + head * 32 + r];
+    const bool online = EPI == LA_CTX && a.kmax == nullptr;       // block-uniform
+    if (EPI == LA_CTX) kmx = online ? -INFINITY : a.kmax[(size_t)n * hd * 32 + head * 32 + r];
     float actx[16];
     if (EPI == LA_QOUT) {
         const float* cb = a.ctx + ((size_t)n * hd + head) * 1024;
@@ -207,6 +211,22 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 for (int i = 0; i < 16; ++i)
                     if (p0 + mt * 32 + acc_row(i, h) < a.hw) run_max = fmaxf(run_max, acc[mt][0][i]);
         } else if (EPI == LA_CTX) {
+            if (online) {
+                // running max of this lane's k channel over the workgroup's pixels; rescale what has been accumulated
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (p0 + mt * 32 + acc_row(i, h) < a.hw) tmax = fmaxf(tmax, acc[mt][0][i]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(kmx, tmax);
+                const float f = (m_new == kmx) ? 1.f : __expf(kmx - m_new);     // kmx = -inf on the first tile -> 0 (accumulators are 0)
+                zsum *= f;
+#pragma unroll
+                for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
+                kmx = m_new;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -250,11 +270,32 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
         if (h == 0) a.kmax_part[((size_t)n * a.S + sidx) * (hd * 32) + head * 32 + r] = run_max;
     } else if (EPI == LA_CTX) {
         zsum += __shfl_xor(zsum, 32);
-        float* cp = a.ctx_part + (((size_t)n * a.S + sidx) * hd + head) * (1024 + 32);
+        float* cp = a.ctx_part + (((size_t)n * a.S + sidx) * hd + head) * (online ? 1024 + 64 : 1024 + 32);
 #pragma unroll
         for (int i = 0; i < 16; ++i) cp[acc_row(i, h) * 32 + r] = cacc[i];
         if (h == 0) cp[1024 + r] = zsum;
+        if (online && h == 0) cp[1056 + r] = kmx;
     }
+}
+
+// merge of the ONLINE context partials [B][S][heads][1024 ctx | 32 z | 32 m]:
+//   M[d] = max_s m_s[d];  ctx[d][e] = sum_s ctx_s[d][e] w_s[d] / (hw * sum_s z_s[d] w_s[d]),  w_s[d] = exp(m_s[d] - M[d])
+__global__ __launch_bounds__(256) void la_ctx_merge_kernel(const float* __restrict__ part, int heads, int S, long long hw,
+                                                           float* __restrict__ ctx) {
+    const int bh = blockIdx.x >> 2, b = bh / heads, head = bh - b * heads;      // 4 blocks per (sample, head)
+    const int i = (blockIdx.x & 3) * 256 + threadIdx.x, d = i >> 5;
+    const size_t stride = (size_t)heads * 1088;
+    const float* base = part + ((size_t)b * S * heads + head) * 1088;
+    float M = -INFINITY;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, base[s * stride + 1056 + d]);
+    float c = 0.f, z = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* cp = base + s * stride;
+        const float w = __expf(cp[1056 + d] - M);
+        c = fmaf(cp[i], w, c);
+        z = fmaf(cp[1024 + d], w, z);
+    }
+    ctx[(size_t)bh * 1024 + i] = c / (z * (float)hw);
 }
 
 // Tiles per workgroup / workgroups per image depend on the image size ONLY (never on B), so the
@@ -296,6 +337,11 @@ int op_linattn_fused(int sweep, const float* x, int C, const float* g, const flo
     if (sweep == LA_KMAX) return launch_la<LA_KMAX>(a, prec, st);
     if (sweep == LA_CTX) return launch_la<LA_CTX>(a, prec, st);
     return launch_la<LA_QOUT>(a, prec, st);
+}
+
+int op_linattn_ctx_merge(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st) {
+    hipLaunchKernelGGL(la_ctx_merge_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    return LAUNCH_OK();
 }
 
 int la_fused_wgs_per_image(int sweep, long long hw) {

@@ -160,7 +160,7 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
-int g_la_fused = 1;   // tedm_set_tuning("la_fused", 0|1): fused linear-attention sweeps vs qkv-tensor path
+int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
 
 }  // namespace
 
@@ -392,18 +392,27 @@ struct Fwd {
             const int S = la_fused_wgs_per_image(0, hw), S2 = la_fused_wgs_per_image(1, hw);
             const float* gpre = u->P(a.pre + ".fn.norm.g");
             const double pf = 2.0 * P * C, pb = 4.0 * P * C;
-            float* kpart = A->alloc((size_t)B * S * u->hidden);
-            float* kmax = A->alloc((size_t)B * u->hidden);
-            OP("linattn_fused<kmax>", pf * u->hidden, pb,
-               op_linattn_fused(0, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st));
-            OP("colmax_finalize", 0.0, 4.0 * B * S * u->hidden, op_colmax_finalize(kpart, S, u->hidden, B, kmax, st));
-            A->release(kpart);
-            float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 32));
             float* ctx = A->alloc((size_t)B * heads * 1024);
-            OP("linattn_fused<ctx>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
-               op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, prec, st));
-            OP("linattn_ctx_finalize", 0.0, 4.0 * B * S2 * heads * 1056, op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx, st));
-            A->release(cpart); A->release(kmax);
+            if (g_la_fused == 2) {
+                // two sweeps: the k-softmax stabiliser is a running per-workgroup max merged by the finalize kernel
+                float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 64));
+                OP("linattn_fused<ctx,online max>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
+                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, prec, st));
+                OP("linattn_ctx_merge", 0.0, 4.0 * B * S2 * heads * 1088, op_linattn_ctx_merge(cpart, B, heads, S2, hw, ctx, st));
+                A->release(cpart);
+            } else {
+                float* kpart = A->alloc((size_t)B * S * u->hidden);
+                float* kmax = A->alloc((size_t)B * u->hidden);
+                OP("linattn_fused<kmax>", pf * u->hidden, pb,
+                   op_linattn_fused(0, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st));
+                OP("colmax_finalize", 0.0, 4.0 * B * S * u->hidden, op_colmax_finalize(kpart, S, u->hidden, B, kmax, st));
+                A->release(kpart);
+                float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 32));
+                OP("linattn_fused<ctx>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
+                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, prec, st));
+                OP("linattn_ctx_finalize", 0.0, 4.0 * B * S2 * heads * 1056, op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx, st));
+                A->release(cpart); A->release(kmax);
+            }
             o = A->alloc((size_t)P * u->hidden);
             OP("linattn_fused<qout>", pf * u->hidden + 2048.0 * P * heads, pb + 4.0 * P * u->hidden,
                op_linattn_fused(2, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx, o, prec, st));
@@ -878,7 +887,7 @@ int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, dou
 int tedm_set_tuning(const char* key, int value) {
     g_err[0] = 0;
     if (!key) return fail(TEDM_EINVAL, "null key");
-    if (!strcmp(key, "la_fused") && (value == 0 || value == 1)) { g_la_fused = value; return TEDM_OK; }
+    if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
@@ -948,12 +957,17 @@ int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* ln
     void* wpk = nullptr; float *kpart = nullptr, *cpart = nullptr;
     const size_t wbytes = conv_packed_bytes(3 * hidden, C, 1);
     if (hipMalloc(&wpk, wbytes) != hipSuccess || hipMalloc((void**)&kpart, (size_t)B * S * hidden * 4) != hipSuccess ||
-        hipMalloc((void**)&cpart, (size_t)B * S2 * heads * 1056 * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+        hipMalloc((void**)&cpart, (size_t)B * S2 * heads * 1088 * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
     int rc = pack_conv_weights(wqkv_oihw, 3 * hidden, C, 1, 1, wpk, prec == TEDM_PREC_FP16X2, st);
     if (rc == TEDM_OK) rc = op_linattn_fused(0, x, C, g, lnstats, wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st);
     if (rc == TEDM_OK) rc = op_colmax_finalize(kpart, S, hidden, B, kmax_out, st);
-    if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, kmax_out, cpart, nullptr, nullptr, prec, st);
-    if (rc == TEDM_OK) rc = op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx_out, st);
+    if (g_la_fused == 2) {                                    // kmax_out above is for the caller only: the context uses the online max
+        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, prec, st);
+        if (rc == TEDM_OK) rc = op_linattn_ctx_merge(cpart, B, heads, S2, hw, ctx_out, st);
+    } else {
+        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, kmax_out, cpart, nullptr, nullptr, prec, st);
+        if (rc == TEDM_OK) rc = op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx_out, st);
+    }
     if (rc == TEDM_OK) rc = op_linattn_fused(2, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx_out, o_out, prec, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(wpk); (void)hipFree(kpart); (void)hipFree(cpart);
