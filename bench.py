@@ -184,6 +184,38 @@ def bench_tedm(args, dm, dp, dist, dev, world, rank):
         dist.destroy_process_group()
 
 
+def bench_sample(args, dm, dp, dist, dev, world, rank):
+    """the serial ancestral-sampling chain (trainers/utils.py:62-98), `args.batch` images per GPU ("replicas only":
+    the chain does not shard).  A step here is ONE denoise step x_t -> x_{t-1} (UNet forward + dynamic thresholding +
+    posterior sample); the chain replays a hipGraph-captured step, the eager rate is reported next to it."""
+    import torch
+    B, S = args.batch, args.size
+    n = max(args.steps, 1)
+    x = torch.randn(B, 1, S, S, device=dev)
+    res = {}
+    with torch.no_grad():
+        for use_graph in (False, True):
+            dm.sample(B, S, steps=max(args.warmup, 2), use_graph=use_graph, x_T=x)           # warm-up (and capture cost for the graph)
+            dp.barrier(dist, dev)
+            t0 = time.perf_counter()
+            out = dm.sample(B, S, steps=n, use_graph=use_graph, x_T=x)
+            dp.barrier(dist, dev)
+            res[use_graph] = dp.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    if rank == 0:
+        el = res[True]
+        print(json.dumps({
+            'metric': 'sampler denoise steps/sec (one x_t -> x_{t-1} step of the ancestral chain, hipGraph replay)',
+            'value': round(world * n / el, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': n, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * el / n, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.prec, 'data': 'synthetic',
+            'config': {'workload': f'DiffusionModel.sample, {B}x1x{S}x{S} per GPU, {n} chain steps (includes one graph capture)',
+                       'eager_ms_per_step': round(1e3 * res[False] / n, 3), 'images_per_s_full_chain_of_1000': round(world * B / (el / n * 1000), 3),
+                       'finite': bool(torch.isfinite(out).all())}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -192,7 +224,7 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
-    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm'],
+    ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
@@ -250,6 +282,8 @@ def main() -> None:
         return bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise)
     if args.mode == 'tedm':
         return bench_tedm(args, dm, dp, dist, dev, world, rank)
+    if args.mode == 'sample':
+        return bench_sample(args, dm, dp, dist, dev, world, rank)
 
     def sync_all():
         dp.barrier(dist, dev)

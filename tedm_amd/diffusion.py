@@ -214,11 +214,12 @@ class DiffusionModel(nn.Module):
 
     @torch.no_grad()
     def sample(self, batch: int, img_size: int, channels: Optional[int] = None, cond: Optional[Tensor] = None,
-               steps: Optional[int] = None, use_graph: bool = True, x_T: Optional[Tensor] = None) -> Tensor:
+               steps: Optional[int] = None, use_graph: bool = False, x_T: Optional[Tensor] = None) -> Tensor:
         """Ancestral sampling x_T -> x_0 over `steps` (default all `timesteps`) serial denoise steps on ONE GPU
-        (the chain does not shard).  The chain is latency bound at small batch (~300 kernel launches
-        per UNet forward), so one step is captured once as a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed
-        with the timestep held in a device tensor."""
+        (the chain does not shard).  `use_graph=True` captures one step (timestep in a device tensor) as a
+        hipGraph (torch.cuda.CUDAGraph on ROCm) and replays it; measured on MI355X the replay is no faster than eager
+        launches (5.7 vs 5.4 ms per step at 4x256x256, `bench.py --mode sample`: dependent-kernel boundaries cost the
+        same in a graph), so eager is the default."""
         dev = next(self.parameters()).device
         ch = channels if channels is not None else self.model.channels
         x = x_T.clone() if x_T is not None else torch.randn(batch, ch, img_size, img_size, device=dev)
