@@ -149,6 +149,18 @@ int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t
 int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const float* p2w, int T, int B,
                  long long chw, float* grad, float* scratch, float* loss, void* stream);
 
+/* ---- stand-alone sub-module forward --------------------------------------------------------------------------------------
+ * The reference's Unet subclasses (models/global_local_cl.py:33-47,75-104) call `block(x, t)` and `attn(x)` on the modules of
+ * `self.downs / mid_* / self.ups` directly.  `module` is the state-dict prefix of a ResnetBlock ("downs.0.0", "mid_block1",
+ * "ups.1.1", "final_res_block") or of a Residual(PreNorm(attention)) block ("downs.0.2", "mid_attn", "ups.3.2").
+ * x1 (| x2): NHWC inputs (x2: second half of a virtual channel concat, or NULL); st_silu: SiLU(time embedding) (B, 4*dim) or
+ * NULL = no FiLM (models/unet_model.py:168); out: NHWC (B,H,W,Cout).  Inference only. */
+int tedm_unet_module_channels(const tedm_unet* h, const char* module, int* cin, int* cout);
+size_t tedm_unet_module_workspace_bytes(const tedm_unet* h, const char* module, int B, int H, int W);
+int tedm_unet_module_forward(tedm_unet* h, const char* module, const float* x1, int C1, const float* x2, int C2,
+                             const float* st_silu, int B, int H, int W, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream, int flags);
+
 /* ---- pixel-classifier head (models/datasetDM_model.py:57-64,85-88) -------------------
  * The head's first layer is a 1x1 conv over the (B, 960*T, S, S) concat of nearest-upsampled decoder taps.  A 1x1 conv
  * commutes with nearest upsampling and distributes over the channel concat:

@@ -47,6 +47,9 @@ _SIGNATURES = {
     'tedm_unet_forward_train': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     'tedm_l1_loss': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, _P, _P, _P, _P]),
+    'tedm_unet_module_channels': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'tedm_unet_module_workspace_bytes': (C.c_size_t, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    'tedm_unet_module_forward': (C.c_int, [_P, C.c_char_p, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     'tedm_conv1x1_packed_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'tedm_conv1x1_pack': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P]),
     'tedm_conv1x1_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P]),

@@ -794,6 +794,95 @@ int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const 
     return rc == TEDM_OK ? rc : fail(rc, "l1 loss launch failed");
 }
 
+// ---- stand-alone sub-module forward (SURVEY 8b "hookable structure": subclasses call block(x, t), attn(x) directly) ----
+// module: a ResnetBlock ("downs.0.0", "mid_block1", "ups.1.1", "final_res_block") or a Residual(PreNorm(attention)) block
+// ("downs.0.2", "mid_attn", "ups.3.2").  x1 (|x2): NHWC inputs (virtual channel concat), st: SiLU(time embedding) (B, 4*dim)
+// or NULL (no FiLM).  out: NHWC (B,H,W,Cout).  Inference only (no tape).
+namespace {
+struct ModuleRef { const ResPlan* res = nullptr; const AttnPlan* attn = nullptr; };
+ModuleRef find_module(const tedm_unet* h, const std::string& name) {
+    ModuleRef m;
+    for (const ResPlan* r : h->resblocks) if (r->pre == name) { m.res = r; return m; }
+    for (const LevelPlan& L : h->downs) if (L.attn.pre == name) { m.attn = &L.attn; return m; }
+    for (const LevelPlan& L : h->ups) if (L.attn.pre == name) { m.attn = &L.attn; return m; }
+    if (h->mid_attn.pre == name) m.attn = &h->mid_attn;
+    return m;
+}
+int run_module(tedm_unet* h, const ModuleRef& m, Arena& A, hipStream_t st, bool dry, const float* x1, int C1, const float* x2, int C2,
+               const float* stv, int B, int H, int W, float* out, int prec) {
+    Fwd f{h, &A, st, dry, B, prec, stv != nullptr, nullptr, false};
+    const long long P = (long long)B * H * W;
+    float* res = nullptr;
+    if (m.res) {
+        if (stv) {
+            f.filmbuf = A.alloc((size_t)B * h->film_J);
+            if (!dry) CHECK(op_film(stv, h->film_w, h->film_b, B, h->tdim, h->film_J, f.filmbuf, st));
+        }
+        CHECK(f.resblock(*m.res, x1, C1, x2, C2, H, W, &res, nullptr));
+        if (!dry) CHECK(copy_rows(res, out, P * m.res->cout, st));
+    } else {
+        float* ln = A.alloc((size_t)P * 2);
+        if (!dry) CHECK(op_ln_stats(x1, ln, P, m.attn->C, st));
+        if (m.attn->linear) CHECK(f.linattn(*m.attn, x1, ln, H, W, out, &res));
+        else {
+            CHECK(f.fullattn(*m.attn, x1, ln, H, W, &res));
+            if (!dry) CHECK(copy_rows(res, out, P * m.attn->C, st));
+        }
+    }
+    return TEDM_OK;
+}
+}  // namespace
+
+int tedm_unet_module_channels(const tedm_unet* h, const char* module, int* cin, int* cout) {
+    g_err[0] = 0;
+    if (!h || !module) return fail(TEDM_EINVAL, "null argument");
+    const ModuleRef m = find_module(h, module);
+    if (!m.res && !m.attn) return fail(TEDM_ENOKEY, "no ResnetBlock / attention block named '%s'", module);
+    if (cin) *cin = m.res ? m.res->cin : m.attn->C;
+    if (cout) *cout = m.res ? m.res->cout : m.attn->C;
+    return TEDM_OK;
+}
+
+size_t tedm_unet_module_workspace_bytes(const tedm_unet* h, const char* module, int B, int H, int W) {
+    g_err[0] = 0;
+    if (!h || !module || B < 1 || H < 1 || W < 1) return 0;
+    const ModuleRef m = find_module(h, module);
+    if (!m.res && !m.attn) return 0;
+    Arena A;
+    A.dry = true;
+    static const float dummy = 0.f;
+    const int C1 = m.res ? m.res->cin : m.attn->C;
+    if (run_module(const_cast<tedm_unet*>(h), m, A, nullptr, true, nullptr, C1, nullptr, 0, &dummy, B, H, W, nullptr, 0) != TEDM_OK) return 0;
+    return A.peak + 256;
+}
+
+int tedm_unet_module_forward(tedm_unet* h, const char* module, const float* x1, int C1, const float* x2, int C2, const float* st_silu,
+                             int B, int H, int W, float* out, void* workspace, size_t workspace_bytes, void* stream, int flags) {
+    g_err[0] = 0;
+    if (!h || !module || !x1 || !out || !workspace) return fail(TEDM_EINVAL, "null argument");
+    if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
+    const ModuleRef m = find_module(h, module);
+    if (!m.res && !m.attn) return fail(TEDM_ENOKEY, "no ResnetBlock / attention block named '%s'", module);
+    const int want = m.res ? m.res->cin : m.attn->C;
+    if (C1 + C2 != want || (m.attn && C2)) return fail(TEDM_EINVAL, "module '%s' takes %d input channels, got %d+%d", module, want, C1, C2);
+    if ((long long)B * H * W >= (1ll << 31)) return fail(TEDM_EINVAL, "B*H*W too large");
+    const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
+    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) return fail(TEDM_ESTATE, "weights are packed for another precision mode");
+    const size_t need = tedm_unet_module_workspace_bytes(h, module, B, H, W);
+    if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
+    if (workspace_bytes < need) return fail(TEDM_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Arena A;
+    const size_t mis = (size_t)((uintptr_t)workspace & 255);
+    A.base = (char*)workspace + (mis ? 256 - mis : 0);
+    A.cap = workspace_bytes - (mis ? 256 - mis : 0);
+    A.dry = false;
+    const int rc = run_module(h, m, A, (hipStream_t)stream, false, x1, C1, x2, C2, st_silu, B, H, W, out, prec);
+    if (rc != TEDM_OK) return rc;
+    if (A.oom) return fail(TEDM_ENOMEM, "workspace overflow");
+    if (hipGetLastError() != hipSuccess) return fail(TEDM_EHIP, "HIP launch error");
+    return TEDM_OK;
+}
+
 // ---- pixel-classifier head building blocks (models/datasetDM_model.py:57-64,85-88) -------------
 size_t tedm_conv1x1_packed_bytes(int Cout, int Cin) { return (Cout % 16 || Cin % 32) ? 0 : conv_packed_bytes(Cout, Cin, 1); }
 

@@ -33,7 +33,20 @@ from . import _lib
 def _native_only(name: str):
     raise NotImplementedError(
         f'{name}: sub-modules of tedm_amd.Unet are parameter containers; the arithmetic runs inside '
-        'Unet.forward (libtedm_hip.so). Stand-alone sub-module calls are not supported.')
+        'Unet.forward (libtedm_hip.so). Only ResnetBlock and the Residual(PreNorm(attention)) blocks can be called '
+        'on their own (forward only, through Unet.module_forward).')
+
+
+def _standalone(mod: nn.Module, x: Tensor, x_extra=None, time_emb: Optional[Tensor] = None) -> Tensor:
+    """Stand-alone call of a ResnetBlock / Residual attention block of a tedm_amd.Unet (models/global_local_cl.py style)."""
+    owner = getattr(mod, '_owner', None)
+    owner = owner[0] if owner else None
+    if owner is None:
+        _native_only(type(mod).__name__)
+    if torch.is_grad_enabled() and (x.requires_grad or (time_emb is not None and time_emb.requires_grad)):
+        raise NotImplementedError('stand-alone sub-module calls are forward-only (the result carries no grad_fn); '
+                                  'train through Unet.forward')
+    return owner.module_forward(mod._qualname, x, time_emb)
 
 
 class _Container(nn.Module):
@@ -82,6 +95,10 @@ class ResnetBlock(_Container):
         self.block2 = Block(dim_out, dim_out, groups=groups)
         self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
+    def forward(self, x: Tensor, time_emb: Optional[Tensor] = None) -> Tensor:
+        """models/unet_model.py:165-175 as one native call (inference only); x may be the torch.cat the reference builds."""
+        return _standalone(self, x, None, time_emb)
+
 
 class LinearAttention(_Container):
     """models/unet_model.py:178-210."""
@@ -127,7 +144,7 @@ class Residual(nn.Module):
 
     def forward(self, x, *args, _native_out: Optional[Tensor] = None, **kwargs):
         if _native_out is None:
-            _native_only('Residual')
+            return _standalone(self, x)                        # attn(x) called directly (models/global_local_cl.py:41,45)
         return _native_out
 
 
@@ -216,6 +233,11 @@ class Unet(nn.Module):
         self._grad_views: Dict[str, Tensor] = {}
         self._grad_handle = None
         self.precision = os.environ.get('TEDM_PREC', 'bf16x3')   # 'bf16x3' (parity mode) | 'bf16'
+        self._module_ws: Optional[Tensor] = None
+        for name, mod in self.named_modules():                  # back-reference for stand-alone calls (not a registered sub-module)
+            if isinstance(mod, (ResnetBlock, Residual)):
+                object.__setattr__(mod, '_owner', (self,))
+                object.__setattr__(mod, '_qualname', name)
         self.last_trace: Dict[str, Tensor] = {}
 
     # -- native handle ---------------------------------------------------------------------
@@ -346,6 +368,41 @@ class Unet(nn.Module):
             if taps is not None:
                 taps = [t.permute(0, 3, 1, 2) for t in taps]     # NCHW-shaped views of the NHWC buffers
         return eps, taps
+
+    # -- stand-alone sub-module calls ----------------------------------------------------------
+    @torch.no_grad()
+    def module_forward(self, name: str, x: Tensor, time_emb: Optional[Tensor] = None) -> Tensor:
+        """Forward of ONE ResnetBlock (`block(x, t)`, t = time embedding or None) or Residual(PreNorm(attention)) block
+        (`attn(x)`) through `tedm_unet_module_forward`.  NCHW in, NCHW-shaped channels-last view out.  Inference only."""
+        if not x.is_cuda:
+            raise RuntimeError('tedm_amd.Unet runs on a ROCm GPU only: there is no CPU fallback')
+        L = _lib.lib()
+        dev = x.device
+        B, Cx, H, W = x.shape
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._ensure_handle(dev)
+            self._sync_params(dev, stream)
+            cin, cout = C.c_int(), C.c_int()
+            _lib.check(L.tedm_unet_module_channels(self._handle, name.encode(), C.byref(cin), C.byref(cout)), f'module {name}')
+            if Cx != cin.value:
+                raise ValueError(f'{name} takes {cin.value} input channels, got {Cx}')
+            xin = x.detach().float().permute(0, 2, 3, 1).contiguous()               # NHWC
+            st = None
+            if time_emb is not None:
+                st = torch.nn.functional.silu(time_emb.detach().float()).contiguous()   # ResnetBlock.mlp's SiLU (:149-152)
+            need = L.tedm_unet_module_workspace_bytes(self._handle, name.encode(), B, H, W)
+            if need == 0:
+                _lib.check(-1, f'module workspace sizing for {name} at {tuple(x.shape)}')
+            if self._module_ws is None or self._module_ws.numel() < need or self._module_ws.device != dev:
+                self._module_ws = None
+                self._module_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            out = torch.empty(B, H, W, cout.value, dtype=torch.float32, device=dev)
+            _lib.check(L.tedm_unet_module_forward(self._handle, name.encode(), xin.data_ptr(), cin.value, None, 0,
+                                                  st.data_ptr() if st is not None else None, B, H, W, out.data_ptr(),
+                                                  self._module_ws.data_ptr(), self._module_ws.numel(), stream,
+                                                  self._flags(False, False)), f'tedm_unet_module_forward({name})')
+        return out.permute(0, 3, 1, 2)
 
     # -- training path ------------------------------------------------------------------------
     def grad_views(self, device: torch.device) -> Dict[str, Tensor]:

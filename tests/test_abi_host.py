@@ -76,8 +76,12 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         with torch.no_grad():
             m(torch.zeros(1, 1, 16, 16), torch.zeros(1))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):        # stand-alone block call: native too
         m.downs[0][0](torch.zeros(1, 32, 16, 16))
+    with pytest.raises(NotImplementedError):                          # inner containers stay containers
+        m.downs[0][0].block1(torch.zeros(1, 32, 16, 16))
+    import copy
+    assert len(copy.deepcopy(m).state_dict()) == 276                   # the owner back-reference survives deepcopy (EMA copies)
     cfg = Namespace(normalize=True, dim=32)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         DiffusionModel(cfg).forward_diffusion_model(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))

@@ -438,3 +438,35 @@ def test_sampler_chain_graph_replay_matches_eager(dev, unet64):
     t2 = time.perf_counter()
     print(f'12-step chain B=2 64x64: graph {1e3 * (t1 - t0):.1f} ms (incl. capture), eager {1e3 * (t2 - t1):.1f} ms')
     assert torch.isfinite(c).all() and torch.isfinite(d).all() and c.abs().max() < 50
+
+
+def test_standalone_submodule_calls_like_global_cl(dev):
+    """models/global_local_cl.py:33-47: a Unet subclass walks init_conv, the encoder blocks, the mid blocks calling
+    block(x, t) / attn(x) / downsample(x) one by one with t = None; plus one block with a time embedding."""
+    from oracle import unet_ref as O
+    m = make_unet(32, 9, dev)
+    p = oracle_weights(m)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 1, 32, 32, generator=g)
+    with torch.no_grad():
+        y = m.init_conv(x.to(dev))                       # plain nn.Conv2d of the facade
+        ref = torch.nn.functional.conv2d(x, p['init_conv.weight'], p['init_conv.bias'], padding=3)
+        for i, (b1, b2, attn, down) in enumerate(m.downs):
+            y = b1(y, None); ref = O.resnet_block(p, f'downs.{i}.0', ref, None, 8)
+            assert rel(y, ref) < MODULE_TOL, f'downs.{i}.0'
+            y = b2(y, None); ref = O.resnet_block(p, f'downs.{i}.1', ref, None, 8)
+            y = attn(y); ref = O.linear_attention(p, f'downs.{i}.2', ref)
+            assert rel(y, ref) < MODULE_TOL, f'downs.{i}.2'
+            y = down(y.contiguous())
+            ref = torch.nn.functional.conv2d(ref, p[f'downs.{i}.3.weight'], p[f'downs.{i}.3.bias'], stride=2 if i < 3 else 1, padding=1)
+        y = m.mid_block1(y, None); ref = O.resnet_block(p, 'mid_block1', ref, None, 8)
+        y = m.mid_attn(y); ref = O.full_attention(p, 'mid_attn', ref)
+        y = m.mid_block2(y, None); ref = O.resnet_block(p, 'mid_block2', ref, None, 8)
+        assert rel(y, ref) < 5 * MODULE_TOL
+        # a decoder block on an explicit torch.cat input, with a time embedding (FiLM)
+        temb = torch.randn(2, 128, generator=g)
+        xin = torch.randn(2, 128 + 64, 8, 8, generator=g)
+        out = m.ups[1][0](xin.to(dev), temb.to(dev))
+        assert rel(out, O.resnet_block(p, 'ups.1.0', xin, temb, 8)) < MODULE_TOL
+    with pytest.raises(NotImplementedError):
+        m.ups[1][0](xin.to(dev).requires_grad_(True), temb.to(dev))
