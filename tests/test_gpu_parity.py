@@ -470,3 +470,22 @@ def test_standalone_submodule_calls_like_global_cl(dev):
         assert rel(out, O.resnet_block(p, 'ups.1.0', xin, temb, 8)) < MODULE_TOL
     with pytest.raises(NotImplementedError):
         m.ups[1][0](xin.to(dev).requires_grad_(True), temb.to(dev))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 8, 8), (3, 1, 8, 24), (1, 1, 16, 8), (2, 1, 40, 72), (5, 1, 56, 56)])
+def test_edge_shapes_vs_oracle(dev, shape):
+    """Minimum size (8x8: the bottleneck is 1x1 and every level is a ragged tile), non-square and non-multiple-of-32
+    images, single-image and odd batches."""
+    from oracle import unet_ref as O
+    m = make_unet(32, 2, dev)
+    g = torch.Generator().manual_seed(sum(shape))
+    x, t = torch.randn(*shape, generator=g), torch.randint(0, 1000, (shape[0],), generator=g)
+    with torch.no_grad():
+        eps = m(x.to(dev), t.to(dev))
+    assert rel(eps, O.unet_forward(oracle_weights(m), x, t, dim=32)) < 1e-4
+
+
+def test_largest_image_512_is_finite(dev, unet64):
+    with torch.no_grad():
+        eps = unet64(torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(3)).to(dev), torch.tensor([500]).to(dev))
+    assert tuple(eps.shape) == (1, 1, 512, 512) and bool(torch.isfinite(eps).all()) and 0.1 < float(eps.abs().mean()) < 10

@@ -199,3 +199,17 @@ def test_trainer_loop_native_path_checkpoint_and_resume(dev, tmp_path):
     cfg2 = Namespace(**{**vars(cfg), 'max_steps': step + 2})
     trainer.train(cfg2, dm2, opt2, loader, None, None, step, on_step=lambda s, l: more.append(s))
     assert more == [step + 1, step + 2]
+
+
+def test_gradients_at_the_minimum_image_size(dev):
+    """8x8 input: 1x1 bottleneck, every conv / weight-gradient tile is ragged."""
+    from tedm_amd import Unet, load_synth_weights
+    m = Unet(32)
+    load_synth_weights(m, seed=2)
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(0)
+    x, t, R = torch.randn(2, 1, 8, 8, generator=g), torch.tensor([1, 999]), torch.randn(2, 1, 8, 8, generator=g)
+    _, gref = oracle_grads(m, x, t, R, 32)
+    m(x.to(dev), t.to(dev)).backward(R.to(dev))
+    worst = max((rel(p.grad, gref[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < GRAD_TOL, worst
