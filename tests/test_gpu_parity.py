@@ -489,3 +489,16 @@ def test_largest_image_512_is_finite(dev, unet64):
     with torch.no_grad():
         eps = unet64(torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(3)).to(dev), torch.tensor([500]).to(dev))
     assert tuple(eps.shape) == (1, 1, 512, 512) and bool(torch.isfinite(eps).all()) and 0.1 < float(eps.abs().mean()) < 10
+
+
+def test_invalid_inputs_fail_loudly(dev, unet64):
+    from tedm_amd import _lib
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            unet64(torch.zeros(1, 2, 16, 16, device=dev), torch.zeros(1, device=dev))            # wrong channel count
+        with pytest.raises(ValueError):
+            unet64(torch.zeros(2, 1, 16, 16, device=dev), torch.zeros(3, device=dev))            # one timestep per image
+        with pytest.raises(_lib.TedmError, match='multiples of 8'):
+            unet64(torch.zeros(1, 1, 12, 16, device=dev), torch.zeros(1, device=dev))            # three stride-2 stages
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            unet64(torch.zeros(1, 1, 16, 16), torch.zeros(1))
