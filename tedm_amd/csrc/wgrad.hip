@@ -189,7 +189,7 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
 // Geometry shared by the launcher and the workspace planner.
 static void wgrad_geometry(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo, int* TR, int* tiles_x, int* tiles_y,
                            int* S, int* tpw) {
-    *TR = stride == 2 ? 1 : 2;
+    *TR = stride == 2 ? 1 : (k == 1 ? 1 : 2);        // 1x1: 32-pixel tiles = 16 KB of LDS, 8 workgroups per CU hide the staging latency (TR 2: +3.5 ms per step)
     *tiles_x = (Wo + 31) / 32;
     *tiles_y = (Ho + *TR - 1) / *TR;
     const long long ntile = (long long)B * *tiles_x * *tiles_y;
@@ -200,7 +200,6 @@ static void wgrad_geometry(int k, int stride, int Cout, int Cin, int B, int Ho, 
     const long long t = (ntile + s - 1) / s;
     *tpw = (int)t;
     *S = (int)((ntile + t - 1) / t);
-    (void)k;
 }
 
 // tedm_set_tuning("wgrad_mfma", v): 0 = exact-fp32 MFMA kernel everywhere, 1 = bf16x3 matrix-core path for 3x3 (default;
@@ -247,8 +246,8 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     else if (k == 3 && stride == 1 && !ups && pro == PRO_GN) rc = launch_wgrad<3, 3, 1, 1, 0, 2, 9, PRO_GN>(a, st);
     else if (k == 3 && stride == 1 && ups == 1 && pro == PRO_NONE) rc = launch_wgrad<3, 3, 1, 1, 1, 2, 9, PRO_NONE>(a, st);
     else if (k == 4 && stride == 2 && !ups && pro == PRO_NONE) rc = launch_wgrad<4, 4, 2, 1, 0, 1, 8, PRO_NONE>(a, st);
-    else if (k == 1 && stride == 1 && !ups && pro == PRO_NONE) rc = launch_wgrad<1, 1, 1, 0, 0, 2, 1, PRO_NONE>(a, st);
-    else if (k == 1 && stride == 1 && !ups && pro == PRO_LN) rc = launch_wgrad<1, 1, 1, 0, 0, 2, 1, PRO_LN>(a, st);
+    else if (k == 1 && stride == 1 && !ups && pro == PRO_NONE) rc = launch_wgrad<1, 1, 1, 0, 0, 1, 1, PRO_NONE>(a, st);
+    else if (k == 1 && stride == 1 && !ups && pro == PRO_LN) rc = launch_wgrad<1, 1, 1, 0, 0, 1, 1, PRO_LN>(a, st);
     if (rc != TEDM_OK) return rc;
     const long long per = (long long)k * k * Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(1024), 0, st, part, a.S, k * k, Cout, Cin, dw,
