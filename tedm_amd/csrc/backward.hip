@@ -618,14 +618,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
             }
 }
 // dW[co][k] (+)= sum_blocks part[block][k][co]
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nb, int K, int Cout, float* __restrict__ dW, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K * Cout) return;
-    const int k = i / Cout, co = i - k * Cout;
+__global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nb, int K, int Cout,
+                                                                 float* __restrict__ dW, int accumulate) {
+    __shared__ float red[16][64];                     // 64 consecutive (k, co) entries x 16 slice lanes, fixed order
+    const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[(size_t)b * K * Cout + i];
-    float* o = dW + (size_t)co * K + k;
-    *o = accumulate ? *o + s : s;
+    if (i < K * Cout)
+        for (int b = sl; b < nb; b += 16) s += part[(size_t)b * K * Cout + i];
+    red[sl][il] = s;
+    __syncthreads();
+    if (sl == 0 && i < K * Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][il];
+        const int k = i / Cout, co = i - k * Cout;
+        float* o = dW + (size_t)co * K + k;
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -650,12 +660,14 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
     for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
     if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = red[0] * wgt;
 }
-__global__ void l1_loss_finalize_kernel(const float* __restrict__ part, int n, float denom, float* __restrict__ loss) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        *loss = (float)(s / denom);
-    }
+__global__ __launch_bounds__(256) void l1_loss_finalize_kernel(const float* __restrict__ part, int n, float denom, float* __restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];          // fixed assignment of entries to threads => deterministic
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(red[0] / denom);
 }
 
 struct PixMap { int lpp, v; };
@@ -816,14 +828,14 @@ int op_stem_wgrad(const float* dY, const float* x_nchw, int B, int Cin, int H, i
         if (!attr) { if (!set_attr((const void*)stem_wgrad_kernel)) return TEDM_EHIP; attr = true; }
         hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb2), dim3(256), lds, st, dY, x_nchw, B, Cin, H, W, Cout, tpb, part);
     }
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((K * Cout + 255) / 256), dim3(256), 0, st, part, slices, K, Cout, dW, accumulate);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((K * Cout + 63) / 64), dim3(1024), 0, st, part, slices, K, Cout, dW, accumulate);
     return LAUNCH_OK();
 }
 // part: B*64 floats
 int op_l1_loss(const float* eps, const float* target, const long long* t, const float* p2w, int T, int B, long long chw,
                float* grad, float* part, float* loss, hipStream_t st) {
     hipLaunchKernelGGL(l1_loss_kernel, dim3(64, B), dim3(256), 0, st, eps, target, t, p2w, T, B, chw, grad, part);
-    hipLaunchKernelGGL(l1_loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, B * 64, (float)B * (float)chw, loss);
+    hipLaunchKernelGGL(l1_loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, B * 64, (float)B * (float)chw, loss);
     return LAUNCH_OK();
 }
 
