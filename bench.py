@@ -223,7 +223,7 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2'])
+    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2', 'f16f4'])
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -328,7 +328,9 @@ def main() -> None:
                    'images_per_gpu': B, 'image_size': S, 'params': 36245377,
                    'precision': {'bf16x3': 'bf16 hi/lo split MFMA (3 products), fp32 accumulate, fp32 activations in HBM',
                                  'bf16': 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM',
-                                 'fp16x2': 'fp16 activations x fp16 hi/lo weights (2 products), fp32 accumulate, fp32 activations in HBM'}[args.prec],
+                                 'fp16x2': 'fp16 activations x fp16 hi/lo weights (2 products), fp32 accumulate, fp32 activations in HBM',
+                                 'f16f4': 'fp16 x fp16 MFMA + one block-scaled fp4 MFMA (K=64) carrying both cross terms of the fp16 split: '
+                                          '1.5 bf16-rate MFMA issues per 16 channels, fp32 accumulate, fp32 activations in HBM'}[args.prec],
                    'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
     }
 
@@ -350,8 +352,8 @@ def main() -> None:
                 'all_conv_tflops': round(sum(e[3] for e in conv_prof) / (conv_ms * 1e-3) / 1e12, 2),
                 # `achieved` counts ALGORITHMIC flops; the parity mode issues 3 bf16 MFMA products per algorithmic product (1 for
                 # --prec bf16, 2 for fp16x2), so the matrix pipes are busy `frac * mfma_products` of the nominal peak
-                'mfma_products': {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1}[args.prec],
-                'frac_of_issued_mfma_peak': round(achieved * {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1}[args.prec] / PEAK_BF16_TFLOPS, 4),
+                'mfma_products': {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec],
+                'frac_of_issued_mfma_peak': round(achieved * {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec] / PEAK_BF16_TFLOPS, 4),
             }
         per_img = elapsed / (B * K)
         scale = (S / 256.0) ** 2

@@ -38,6 +38,9 @@ extern "C" {
 #define TEDM_PREC_BF16X3   0   /* default: bf16 hi/lo split, 3 MFMAs, fp32 accumulate (~2^-17 operand error) */
 #define TEDM_PREC_BF16     1   /* single bf16 MFMA, fp32 accumulate (fast; eps error ~1e-2, fails the 1e-3 gate) */
 #define TEDM_PREC_FP16X2   2   /* fp16 activations x (fp16 hi + fp16 lo) weights, 2 MFMAs, fp32 accumulate (experimental) */
+#define TEDM_PREC_F16F4    3   /* fp16 x fp16 MFMA + ONE block-scaled fp4 MFMA (K = 64) carrying both cross terms
+                                  A_lo*B + A*B_lo of the fp16 split: 1.5 bf16-MFMA issues per 16 channels instead of 3;
+                                  eps error ~2-3e-4 (inside the 1e-3 gate) */
 
 /* forward flags */
 #define TEDM_FWD_TAPS_ONLY   (1 << 0)  /* skip ups[last][3], final_res_block, final_conv (feature extraction; eps_out may be NULL) */

@@ -17,7 +17,7 @@ ROOT = PKG.parent
 CSRC = PKG / 'csrc'
 OBJ = CSRC / 'build'
 LIB = PKG / 'libtedm_hip.so'
-SOURCES = ['conv_igemm.hip', 'pack.hip', 'elementwise.hip', 'attention.hip', 'linattn_fused.hip', 'wgrad.hip', 'wgrad_mfma.hip', 'backward.hip', 'attention_bwd.hip', 'unet_host.hip']
+SOURCES = ['conv_igemm_p0.hip', 'conv_igemm_p1.hip', 'conv_igemm_p2.hip', 'conv_igemm_p3.hip', 'conv_igemm.hip', 'pack.hip', 'elementwise.hip', 'attention.hip', 'linattn_fused.hip', 'wgrad.hip', 'wgrad_mfma.hip', 'backward.hip', 'attention_bwd.hip', 'unet_host.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
@@ -29,7 +29,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> list:
-    return sorted(CSRC.glob('*.hip')) + sorted(CSRC.glob('*.h')) + sorted((ROOT / 'include').glob('*.h'))
+    return sorted(CSRC.glob('*.hip')) + sorted(CSRC.glob('*.h')) + sorted(CSRC.glob('*.inc')) + sorted((ROOT / 'include').glob('*.h'))
 
 
 def needs_build() -> bool:
@@ -41,7 +41,7 @@ def needs_build() -> bool:
 
 def _compile(src: str) -> Path:
     obj = OBJ / (src + '.o')
-    deps = [CSRC / src] + sorted(CSRC.glob('*.h')) + sorted((ROOT / 'include').glob('*.h'))
+    deps = [CSRC / src] + sorted(CSRC.glob('*.h')) + sorted(CSRC.glob('*.inc')) + sorted((ROOT / 'include').glob('*.h'))
     if obj.exists() and all(p.stat().st_mtime <= obj.stat().st_mtime for p in deps):
         return obj
     cmd = [_hipcc(), *FLAGS, '-c', str(CSRC / src), '-o', str(obj)]
@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if force:
         for o in OBJ.glob('*.o'):
             o.unlink()
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -47,6 +47,52 @@ TEDM_DEVFN uint4 cvt8_f16(const float (&v)[8]) {
     return __builtin_bit_cast(uint4, h);
 }
 
+// ---- TEDM_PREC_F16F4 operand encoding --------------------------------------------------------------------
+// A 32-channel block of an operand is carried as  fp16 hi (11 significand bits)  +  two MX-fp4 (e2m1, E8M0 block scale)
+// blocks: `lo4` = fp4(v - hi) and `v4` = fp4(v).  One v_mfma_scale_f32_32x32x64_f8f6f4 then adds BOTH cross terms of
+//   A*B ~= Ah*Bh + Al*B4 + A4*Bl
+// in a single 32-cycle issue: its K = 64 is the concatenation [Al | A4] x [B4 ; Bl] (lanes 0-31 hold k-slots 0-31, lanes
+// 32-63 k-slots 32-63, one scale byte per lane = per 32-slot block; layout pinned on hardware by tools/mfma_probe.hip).
+// Per 32 channels: 2 f16 MFMAs + 1 fp4 MFMA = 96 matrix-pipe cycles instead of the 192 of bf16x3; eps error 2-2.6e-4
+// against the fp32 reference (tools/precision_study.py), gate 1e-3.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+TEDM_DEVFN float quad_max(float v) {      // max over the aligned group of 4 lanes (DPP quad_perm, no LDS)
+    int x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));   // [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));  // [2,3,0,1]
+}
+// E8M0 scale bytes of a block whose largest magnitude is `amax`: the fp4 copy is scaled by 2^(floor(log2 amax) - 2)
+// (OCP MX rule, e2m1 emax = 2, saturating), the fp4 residual by the fp16 half-ulp bound 2^(E-11) (2^-25 in fp16's
+// subnormal range) with the same emax.
+TEDM_DEVFN void f4_scales(float amax, unsigned& e_v4, unsigned& e_lo) {
+    const int E = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+    int a = E - 2, l = (E - 11 > 102 ? E - 11 : 102) - 2;
+    e_v4 = (unsigned)(a < 1 ? 1 : a);
+    e_lo = (unsigned)(l < 1 ? 1 : l);
+}
+TEDM_DEVFN unsigned cvt8_fp4(const float (&v)[8], unsigned e8m0) {
+    const float sc = __builtin_bit_cast(float, e8m0 << 23);
+    unsigned u = 0;
+    u = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(u, v[0], v[1], sc, 0);
+    u = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(u, v[2], v[3], sc, 1);
+    u = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(u, v[4], v[5], sc, 2);
+    u = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(u, v[6], v[7], sc, 3);
+    return u;
+}
+// fp16 hi (finite: clamped to +-65504) and the fp32 residual of 8 values
+TEDM_DEVFN uint4 split8_f16_res(const float (&v)[8], float (&lo)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)__builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+        h[j] = hj;
+        lo[j] = v[j] - (float)hj;
+    }
+    return __builtin_bit_cast(uint4, h);
+}
+
 TEDM_DEVFN float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -100,7 +146,10 @@ size_t conv_packed_bytes(int Cout, int Cin, int taps);
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap);
 
 // ---- pack.hip -------------------------------------------------------------------------
-int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int fp16, hipStream_t st);
-int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int fp16,
+// Weight encodings (which packed layout a TEDM_PREC_* mode consumes): bf16 hi/lo planes, fp16 hi/lo planes, fp16 + fp4.
+enum { ENC_BF16 = 0, ENC_F16 = 1, ENC_F16F4 = 2 };
+inline int prec_encoding(int prec) { return prec == 2 /*FP16X2*/ ? ENC_F16 : (prec == 3 /*F16F4*/ ? ENC_F16F4 : ENC_BF16); }
+int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int enc, hipStream_t st);
+int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int enc,
                             hipStream_t st);
 int copy_rows(const float* src, float* dst, long long n, hipStream_t st);

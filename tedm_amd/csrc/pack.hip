@@ -65,6 +65,79 @@ __global__ void conv_pack_dgrad_kernel(const float* __restrict__ w, int Cout, in
     wpk[(q + 1) * 64 + lane] = lo;
 }
 
+// TEDM_PREC_F16F4 (common.h): per (cout tile, 32-channel chunk, tap) three 1-KB fragments
+//   f = 0,1: fp16 B fragments of v_mfma_f32_32x32x16_f16 for channels [0,16) / [16,32) of the chunk
+//   f = 2  : fp4 B fragment of v_mfma_scale_f32_32x32x64_f8f6f4: lanes 0-31 (k-slots 0-31, multiplied with the
+//            activations' fp4 RESIDUAL block) hold fp4(W), lanes 32-63 (k-slots 32-63, multiplied with the activations'
+//            fp4 COPY block) hold fp4(W - fp16(W))
+// followed, after all fragments, by the E8M0 scale bytes: one dword per (cout tile, chunk, kx, lane), byte ky = scale of
+// this lane's block for tap (ky, kx) -- the MFMA's op_sel picks the byte, so one register serves a whole tap column.
+template <typename F>
+__device__ void pack_f16f4_lane(F fetch, int lane, int KH, int KW, int tap, size_t frag0, size_t sdw, uint4* wpk, unsigned char* sc) {
+    const int h = lane >> 5;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { v[i] = fetch(i); amax = fmaxf(amax, fabsf(v[i])); }
+    unsigned e_v4, e_lo;
+    f4_scales(amax, e_v4, e_lo);
+    uint4 q;
+    unsigned* qw = (unsigned*)&q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float x[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v[g * 8 + j];
+        const uint4 hi = split8_f16_res(x, lo);
+        // fp16 fragment element j of lane half hh of k-step ks is channel ks*16 + 8*hh + j: group g = 2*ks + hh
+        if ((g & 1) == h) wpk[(frag0 + (g >> 1)) * 64 + lane] = hi;
+        qw[g] = h == 0 ? cvt8_fp4(x, e_v4) : cvt8_fp4(lo, e_lo);
+    }
+    wpk[(frag0 + 2) * 64 + lane] = q;
+    const int ky = tap / KW;
+    sc[(sdw * 64 + lane) * 4 + ky] = (unsigned char)(h == 0 ? e_v4 : e_lo);
+    (void)KH;
+}
+
+__global__ void conv_pack_f16f4_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, uint4* __restrict__ wpk,
+                                       long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int T = KH * KW;
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int tap = (int)(f % T); f /= T;
+    const int NC = Cin / 32;
+    const int c = (int)(f % NC);
+    const int ct = (int)(f / NC);
+    const int cout = ct * 32 + (lane & 31);
+    const long long CT = (Cout + 31) / 32;
+    unsigned char* sc = (unsigned char*)(wpk + (size_t)CT * NC * T * 3 * 64);
+    const int kx = tap % KW;
+    pack_f16f4_lane([&](int k) { return cout < Cout ? w[((size_t)cout * Cin + c * 32 + k) * T + tap] : 0.f; },
+                    lane, KH, KW, tap, (((size_t)ct * NC + c) * T + tap) * 3, ((size_t)ct * NC + c) * KW + kx, wpk, sc);
+}
+
+__global__ void conv_pack_dgrad_f16f4_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int ci0, int nci,
+                                             uint4* __restrict__ wpk, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int T = KH * KW;
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int tap = (int)(f % T); f /= T;
+    const int NC = Cout / 32;                          // dgrad reduces over the original output channels
+    const int c = (int)(f % NC);
+    const int ct = (int)(f / NC);
+    const int o = ct * 32 + (lane & 31);
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const int otap = (KH - 1 - ky) * KW + (KW - 1 - kx);
+    const long long CT = (nci + 31) / 32;
+    unsigned char* sc = (unsigned char*)(wpk + (size_t)CT * NC * T * 3 * 64);
+    pack_f16f4_lane([&](int k) { return o < nci ? w[((size_t)(c * 32 + k) * Cin + ci0 + o) * T + otap] : 0.f; },
+                    lane, KH, KW, tap, (((size_t)ct * NC + c) * T + tap) * 3, ((size_t)ct * NC + c) * KW + kx, wpk, sc);
+}
+
 __global__ void copy_kernel(const float* __restrict__ s, float* __restrict__ d, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -72,20 +145,36 @@ __global__ void copy_kernel(const float* __restrict__ s, float* __restrict__ d, 
 
 }  // namespace
 
-int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int fp16, hipStream_t st) {
+int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int enc, hipStream_t st) {
     if (Cin % 16) return TEDM_EINVAL;
     const int T = KH * KW;
     const long long CT = (Cout + 31) / 32;
+    if (enc == ENC_F16F4) {
+        if (Cin % 32 || KH > 4) return TEDM_EINVAL;
+        const long long total = CT * (Cin / 32) * T * 64;
+        hipLaunchKernelGGL(conv_pack_f16f4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           w, Cout, Cin, KH, KW, (uint4*)wpk, total);
+        return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+    }
+    const int fp16 = enc == ENC_F16;
     const long long total = CT * (Cin / 16) * T * 64;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        w, Cout, Cin, T, (uint4*)wpk, total, fp16);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
 
-int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int fp16,
+int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int enc,
                             hipStream_t st) {
     if (Cout % 16 || ci0 < 0 || ci0 + nci > Cin) return TEDM_EINVAL;
     const long long CT = (nci + 31) / 32;
+    if (enc == ENC_F16F4) {
+        if (Cout % 32 || KH > 4) return TEDM_EINVAL;
+        const long long total = CT * (Cout / 32) * KH * KW * 64;
+        hipLaunchKernelGGL(conv_pack_dgrad_f16f4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           w, Cout, Cin, KH, KW, ci0, nci, (uint4*)wpk, total);
+        return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+    }
+    const int fp16 = enc == ENC_F16;
     const long long total = CT * (Cout / 16) * KH * KW * 64;
     hipLaunchKernelGGL(conv_pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        w, Cout, Cin, KH, KW, ci0, nci, (uint4*)wpk, total, fp16);

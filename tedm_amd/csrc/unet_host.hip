@@ -45,6 +45,8 @@ struct ConvW {           // one conv weight in packed MFMA-fragment form (handle
     bool has_bias = true;
     void* wpk = nullptr;
     size_t bytes = 0;
+    int enc = ENC_BF16;  // encoding of wpk / wpk_d (set by the pack calls; the conv launch derives its arithmetic mode from it)
+    bool la_qkv = false; // to_qkv of a LinearAttention: consumed by linattn_fused.hip, which reads bf16 hi/lo planes
     // training: data-gradient packs (flipped taps, Cin<->Cout swapped).  Convs over a virtual channel concat
     // [x1 (split channels) | x2] carry one pack per input so that each dX is its own launch.
     int split = 0;
@@ -226,6 +228,7 @@ struct tedm_unet {
     void add_attn(AttnPlan& a, const std::string& pre, int C, bool linear) {
         a.pre = pre; a.C = C; a.linear = linear;
         add_conv(a.qkv, pre + ".fn.fn.to_qkv", 3 * hidden, C, 1, false);
+        a.qkv.la_qkv = linear;
         if (linear) {
             add_conv(a.out, pre + ".fn.fn.to_out.0", C, hidden, 1, true);
             add_param(pre + ".fn.fn.to_out.1.g", C);
@@ -304,6 +307,12 @@ int build_plan(tedm_unet* u) {
     return TEDM_OK;
 }
 
+// Arithmetic mode of one conv launch: the handle's mode, except that a weight kept in bf16 planes under F16F4 (the
+// LinearAttention to_qkv, shared with linattn_fused.hip) runs bf16x3.
+inline int conv_prec(const ConvW& w, int prec) { return (prec == TEDM_PREC_F16F4 && w.enc == ENC_BF16) ? TEDM_PREC_BF16X3 : prec; }
+inline int la_prec(int prec) { return prec == TEDM_PREC_F16F4 ? TEDM_PREC_BF16X3 : prec; }
+inline bool prec_ok(int prec) { return prec == TEDM_PREC_BF16X3 || prec == TEDM_PREC_BF16 || prec == TEDM_PREC_FP16X2 || prec == TEDM_PREC_F16F4; }
+
 #define OP(NAME, FLOPS, BYTES, CALL)                                              \
     do {                                                                          \
         if (!dry) {                                                               \
@@ -325,7 +334,7 @@ struct Fwd {
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = w.cout;
         a.wpk = w.wpk; a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
         a.pro_a = pa; a.pro_b = pb; a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b;
-        a.stats = stats; a.stats_mode = stats_mode; a.prec = prec;
+        a.stats = stats; a.stats_mode = stats_mode; a.prec = conv_prec(w, prec);
         if (g_prof.level >= 1) {
             char label[160];
             conv_kernel_label(a, w.k, stride, ups, pro, label, sizeof(label));
@@ -397,25 +406,25 @@ struct Fwd {
                 // two sweeps: the k-softmax stabiliser is a running per-workgroup max merged by the finalize kernel
                 float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 64));
                 OP("linattn_fused<ctx,online max>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
-                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, prec, st));
+                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, la_prec(prec), st));
                 OP("linattn_ctx_merge", 0.0, 4.0 * B * S2 * heads * 1088, op_linattn_ctx_merge(cpart, B, heads, S2, hw, ctx, st));
                 A->release(cpart);
             } else {
                 float* kpart = A->alloc((size_t)B * S * u->hidden);
                 float* kmax = A->alloc((size_t)B * u->hidden);
                 OP("linattn_fused<kmax>", pf * u->hidden, pb,
-                   op_linattn_fused(0, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st));
+                   op_linattn_fused(0, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, la_prec(prec), st));
                 OP("colmax_finalize", 0.0, 4.0 * B * S * u->hidden, op_colmax_finalize(kpart, S, u->hidden, B, kmax, st));
                 A->release(kpart);
                 float* cpart = A->alloc((size_t)B * S2 * heads * (1024 + 32));
                 OP("linattn_fused<ctx>", pf * 2 * u->hidden + 2048.0 * P * heads, pb,
-                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, prec, st));
+                   op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, la_prec(prec), st));
                 OP("linattn_ctx_finalize", 0.0, 4.0 * B * S2 * heads * 1056, op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx, st));
                 A->release(cpart); A->release(kmax);
             }
             o = A->alloc((size_t)P * u->hidden);
             OP("linattn_fused<qout>", pf * u->hidden + 2048.0 * P * heads, pb + 4.0 * P * u->hidden,
-               op_linattn_fused(2, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx, o, prec, st));
+               op_linattn_fused(2, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx, o, la_prec(prec), st));
             A->release(ctx);
         } else {
             float* qkv = A->alloc((size_t)P * C3);
@@ -629,8 +638,10 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM weights failed");
     if (!h->film_b && hipMalloc((void**)&h->film_b, (size_t)h->film_J * 4) != hipSuccess)
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
-    for (ConvW* c : h->convs)
-        CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, h->prec == TEDM_PREC_FP16X2, st));
+    for (ConvW* c : h->convs) {
+        c->enc = (h->prec == TEDM_PREC_F16F4 && c->la_qkv) ? ENC_BF16 : prec_encoding(h->prec);
+        CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, c->enc, st));
+    }
     for (ResPlan* r : h->resblocks) {
         CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.weight"), h->film_w + (size_t)r->film_off * h->tdim, (long long)2 * r->cout * h->tdim, st));
         CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.bias"), h->film_b + r->film_off, 2 * r->cout, st));
@@ -642,8 +653,8 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
 int tedm_unet_set_precision(tedm_unet* h, int prec) {
     g_err[0] = 0;
     if (!h) return fail(TEDM_EINVAL, "null handle");
-    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
-    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) { h->packed = false; h->packed_bwd = false; }
+    if (!prec_ok(prec)) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if (prec_encoding(prec) != prec_encoding(h->prec)) { h->packed = false; h->packed_bwd = false; }
     h->prec = prec;
     return TEDM_OK;
 }
@@ -668,8 +679,8 @@ int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H
     if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
     CHECK(check_shape(h, B, H, W));
     const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
-    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
-    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2))
+    if (!prec_ok(prec)) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if (prec_encoding(prec) != prec_encoding(h->prec))
         return fail(TEDM_ESTATE, "weights are packed for precision mode %d, forward asks for %d: call tedm_unet_set_precision + tedm_unet_pack", h->prec, prec);
     Arena A;
     const size_t mis = (size_t)((uintptr_t)workspace & 255);
@@ -705,7 +716,7 @@ int tedm_unet_pack_backward(tedm_unet* h, void* stream) {
     g_err[0] = 0;
     if (!h) return fail(TEDM_EINVAL, "null handle");
     hipStream_t st = (hipStream_t)stream;
-    const int fp16 = h->prec == TEDM_PREC_FP16X2;
+    const int fp16 = prec_encoding(h->prec);   // encoding of the data-gradient packs
     for (ConvW* c : h->convs) {
         const float* w = h->P(c->key + ".weight");
         if (!w) return fail(TEDM_ESTATE, "parameter '%s.weight' is not bound", c->key.c_str());
@@ -742,8 +753,8 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
     if (!h->packed) return fail(TEDM_ESTATE, "tedm_unet_pack() has not been called since parameters were (re)bound");
     CHECK(check_shape(h, B, H, W));
     const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
-    if (prec != TEDM_PREC_BF16X3 && prec != TEDM_PREC_BF16 && prec != TEDM_PREC_FP16X2) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
-    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2))
+    if (!prec_ok(prec)) return fail(TEDM_EINVAL, "unknown precision mode %d", prec);
+    if (prec_encoding(prec) != prec_encoding(h->prec))
         return fail(TEDM_ESTATE, "weights are packed for precision mode %d, forward asks for %d", h->prec, prec);
     const size_t need = tedm_unet_train_workspace_bytes(h, B, H, W);
     if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
@@ -867,7 +878,7 @@ int tedm_unet_module_forward(tedm_unet* h, const char* module, const float* x1, 
     if (C1 + C2 != want || (m.attn && C2)) return fail(TEDM_EINVAL, "module '%s' takes %d input channels, got %d+%d", module, want, C1, C2);
     if ((long long)B * H * W >= (1ll << 31)) return fail(TEDM_EINVAL, "B*H*W too large");
     const int prec = (flags >> TEDM_FWD_PREC_SHIFT) & 0xf;
-    if ((prec == TEDM_PREC_FP16X2) != (h->prec == TEDM_PREC_FP16X2)) return fail(TEDM_ESTATE, "weights are packed for another precision mode");
+    if (prec_encoding(prec) != prec_encoding(h->prec)) return fail(TEDM_ESTATE, "weights are packed for another precision mode");
     const size_t need = tedm_unet_module_workspace_bytes(h, module, B, H, W);
     if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
     if (workspace_bytes < need) return fail(TEDM_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -889,7 +900,7 @@ size_t tedm_conv1x1_packed_bytes(int Cout, int Cin) { return (Cout % 16 || Cin %
 int tedm_conv1x1_pack(const float* w, int Cout, int Cin, void* wpk, int prec, void* stream) {
     g_err[0] = 0;
     if (!w || !wpk || Cout % 16 || Cin % 32) return fail(TEDM_EINVAL, "conv1x1 pack: Cout %% 16 and Cin %% 32 required (got %d, %d)", Cout, Cin);
-    const int rc = pack_conv_weights(w, Cout, Cin, 1, 1, wpk, prec == TEDM_PREC_FP16X2, (hipStream_t)stream);
+    const int rc = pack_conv_weights(w, Cout, Cin, 1, 1, wpk, prec_encoding(prec), (hipStream_t)stream);
     return rc == TEDM_OK ? rc : fail(rc, "conv1x1 pack failed");
 }
 
@@ -998,7 +1009,7 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     void* wpk = nullptr;
     const size_t bytes = conv_packed_bytes(Cout, Cin, k * k);
     if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec == TEDM_PREC_FP16X2, st);
+    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
     if (rc == TEDM_OK) {
         ConvArgs a{};
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -1047,17 +1058,17 @@ int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* ln
     const size_t wbytes = conv_packed_bytes(3 * hidden, C, 1);
     if (hipMalloc(&wpk, wbytes) != hipSuccess || hipMalloc((void**)&kpart, (size_t)B * S * hidden * 4) != hipSuccess ||
         hipMalloc((void**)&cpart, (size_t)B * S2 * heads * 1088 * 4) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-    int rc = pack_conv_weights(wqkv_oihw, 3 * hidden, C, 1, 1, wpk, prec == TEDM_PREC_FP16X2, st);
-    if (rc == TEDM_OK) rc = op_linattn_fused(0, x, C, g, lnstats, wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, prec, st);
+    int rc = pack_conv_weights(wqkv_oihw, 3 * hidden, C, 1, 1, wpk, prec_encoding(la_prec(prec)), st);
+    if (rc == TEDM_OK) rc = op_linattn_fused(0, x, C, g, lnstats, wpk, B, hw, heads, kpart, nullptr, nullptr, nullptr, nullptr, la_prec(prec), st);
     if (rc == TEDM_OK) rc = op_colmax_finalize(kpart, S, hidden, B, kmax_out, st);
     if (g_la_fused == 2) {                                    // kmax_out above is for the caller only: the context uses the online max
-        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, prec, st);
+        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, cpart, nullptr, nullptr, la_prec(prec), st);
         if (rc == TEDM_OK) rc = op_linattn_ctx_merge(cpart, B, heads, S2, hw, ctx_out, st);
     } else {
-        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, kmax_out, cpart, nullptr, nullptr, prec, st);
+        if (rc == TEDM_OK) rc = op_linattn_fused(1, x, C, g, lnstats, wpk, B, hw, heads, nullptr, kmax_out, cpart, nullptr, nullptr, la_prec(prec), st);
         if (rc == TEDM_OK) rc = op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx_out, st);
     }
-    if (rc == TEDM_OK) rc = op_linattn_fused(2, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx_out, o_out, prec, st);
+    if (rc == TEDM_OK) rc = op_linattn_fused(2, x, C, g, lnstats, wpk, B, hw, heads, nullptr, nullptr, nullptr, ctx_out, o_out, la_prec(prec), st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(wpk); (void)hipFree(kpart); (void)hipFree(cpart);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_linattn_fused failed (%d)", rc);
@@ -1080,7 +1091,7 @@ int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight
     if (dx) {
         const size_t bytes = conv_packed_bytes(Cin, Cout, k * k);
         if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-        rc = pack_conv_weights_dgrad(weight_oihw, Cout, Cin, k, k, 0, Cin, wpk, prec == TEDM_PREC_FP16X2, st);
+        rc = pack_conv_weights_dgrad(weight_oihw, Cout, Cin, k, k, 0, Cin, wpk, prec_encoding(prec), st);
         ConvArgs a{};
         a.x1 = dy; a.C1 = Cout; a.B = B; a.H = Ho; a.W = Wo; a.Cout = Cin; a.wpk = wpk; a.prec = prec;
         if (rc == TEDM_OK) {

@@ -115,6 +115,56 @@ def test_conv_igemm_plain(lib, dev, case):
     assert 1e-4 < rel(outb, ref) < 2e-2
 
 
+F4_TOL = 2e-4           # single conv, f16f4: fp16 main product + fp4 cross terms (operand error ~2^-14)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'k{}s{}u{}_{}+{}to{}_{}x{}'.format(*c[:8]))
+def test_conv_igemm_f16f4(lib, dev, case):
+    """TEDM_PREC_F16F4: against fp64 (tolerance of the encoding) and against a CPU emulation of the exact encoding
+    (fragment / nibble / scale-byte layout: any slip shows as an O(1e-3+) difference)."""
+    from f16f4_emul import conv2d as emul_conv
+    k, stride, ups, C1, C2, Cout, H, W, B = case
+    if (C1 + C2) % 32 or C1 % 32:
+        pytest.skip('f16f4 stages 32-channel blocks')
+    x1 = rnd(B, C1, H, W, seed=1)
+    x2 = rnd(B, C2, H, W, seed=2) if C2 else None
+    w = rnd(Cout, C1 + C2, k, k, seed=3, scale=(1.0 / ((C1 + C2) * k * k)) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.1)
+    xin = torch.cat((x1, x2), 1) if C2 else x1
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    pad = {3: 1, 4: 1, 1: 0}[k]
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad)
+    out, st = run_conv(lib, dev, x1, x2, w, b, k, stride, ups, stats_mode=1, prec=3)
+    assert torch.isfinite(out).all()
+    e_ref, e_emu = rel(out, ref), rel(out, emul_conv(xin, w, b, stride, pad))
+    print(f'f16f4 conv: vs fp64 {e_ref:.2e}, vs encoding emulation {e_emu:.2e}')
+    assert e_ref < F4_TOL
+    assert e_emu < 2e-6
+    assert rel(st[..., 1].sum(1), (ref ** 2).sum(dim=(2, 3))) < 1e-3
+    out1, _ = run_conv(lib, dev, x1, x2, w, b, k, stride, ups, stats_mode=2, prec=3)
+    assert torch.equal(out1, out)                      # bitwise reproducible
+
+
+def test_conv_f16f4_scales_and_ranges(lib, dev):
+    """Block scales must follow the data: per-pixel magnitudes from 1e-6 to 1e2 (x37 in a few channels; fp16 hi saturates
+    at 65504) in one tile, one huge and one tiny weight row."""
+    from f16f4_emul import conv2d as emul_conv
+    B, Cc, H, W = 1, 64, 16, 32
+    x = rnd(B, Cc, H, W, seed=7)
+    mag = torch.logspace(-6, 2, H * W).reshape(1, 1, H, W)
+    x = x * mag
+    x[:, 5:9] *= 37.0                                  # a few dominant channels inside a block
+    w = rnd(96, Cc, 3, 3, seed=8, scale=0.05)
+    w[3] *= 1e3
+    w[17] *= 1e-4
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    out, _ = run_conv(lib, dev, x, None, w, None, 3, 1, prec=3)
+    assert torch.isfinite(out).all()
+    assert rel(out, emul_conv(x, w, None, 1, 1)) < 2e-6
+    assert rel(out, ref) < 3e-4
+
+
 def test_conv_identity_weight_asymmetric(lib, dev):
     """A = I style check with asymmetric data (cdna guide section 3): a transposed fragment map cannot pass."""
     B, Cc, H, W = 1, 64, 8, 32
@@ -130,6 +180,11 @@ def test_conv_identity_weight_asymmetric(lib, dev):
         w2[o, o, 0, 2] = 1.0                            # shift: out(y,x) = in(y-1, x+1)
     out2, _ = run_conv(lib, dev, x, None, w2, None, 3, 1)
     assert torch.equal(out2, F.conv2d(x, w2, None, padding=1))
+    # the same in f16f4: integers below 2048 and unit weights are exact in fp16, the fp4 terms vanish or are exact
+    out3, _ = run_conv(lib, dev, x, None, w, None, 3, 1, prec=3)
+    assert torch.equal(out3, ref)
+    out4, _ = run_conv(lib, dev, x, None, w2, None, 3, 1, prec=3)
+    assert torch.equal(out4, F.conv2d(x, w2, None, padding=1))
 
 
 def test_conv_prologues_and_epilogues(lib, dev):
@@ -284,7 +339,7 @@ def test_precision_modes(dev, golden_dir, unet64):
     x, t = torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev)
     errs = {}
     try:
-        for mode in ('bf16', 'fp16x2', 'bf16x3'):
+        for mode in ('bf16', 'fp16x2', 'f16f4', 'bf16x3'):
             unet64.precision = mode
             with torch.no_grad():
                 errs[mode] = rel(unet64(x, t), g['eps'])
@@ -294,6 +349,7 @@ def test_precision_modes(dev, golden_dir, unet64):
     assert errs['bf16x3'] < EPS_GATE / 10
     assert errs['bf16x3'] < errs['fp16x2'] < errs['bf16'] < 0.1
     assert errs['fp16x2'] < 3e-3
+    assert errs['f16f4'] < EPS_GATE / 3               # 2e-4 predicted by tools/precision_study.py
 
 
 def test_vs_oracle_ragged_shape(dev, unet64):

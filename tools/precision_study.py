@@ -1,0 +1,154 @@
+"""CPU study (test infrastructure, not product): which MFMA operand formats keep eps under the 1e-3 gate?
+
+Monkeypatches F.conv2d inside the oracle so that every convolution's operands are rounded the way a
+candidate MFMA scheme would round them, and prints the eps rel-L2 against the untouched fp32 oracle
+on the golden 64x64 inputs.  Run: python tools/precision_study.py [scheme ...]
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import unet_ref as O                     # noqa: E402
+from tedm_amd.weights import synth_state_dict        # noqa: E402
+
+_conv = F.conv2d
+
+
+def bf16(x): return x.to(torch.bfloat16).float()
+def fp16(x): return x.half().float()
+
+
+def minifloat(x, ebits, mbits, bias, vmax):
+    """round-to-nearest-even to a sign/ebits/mbits minifloat with subnormals, saturating at vmax"""
+    ax = x.abs().clamp(min=1e-45)
+    e = torch.floor(torch.log2(ax)).clamp(min=1 - bias)
+    step = torch.exp2(e - mbits)
+    q = torch.round(x / step) * step
+    return q.clamp(-vmax, vmax)
+
+
+def bf8(x): return minifloat(x, 5, 2, 15, 57344.0)
+def fp8(x): return minifloat(x, 4, 3, 7, 448.0)
+
+
+def mx(x, dim, kind, block=32):
+    """OCP-MX block quantisation along `dim` in blocks of `block` with an E8M0 shared scale."""
+    ebits, mbits, bias, vmax, emax = {'fp6': (2, 3, 1, 7.5, 2), 'bf6': (3, 2, 3, 28.0, 4),
+                                      'fp4': (2, 1, 1, 6.0, 2), 'fp8': (4, 3, 7, 448.0, 8),
+                                      'bf8': (5, 2, 15, 57344.0, 15)}[kind]
+    xm = x.movedim(dim, -1)
+    shp = xm.shape
+    C = shp[-1]
+    pad = (-C) % block
+    if pad:
+        xm = F.pad(xm, (0, pad))
+    xb = xm.reshape(*xm.shape[:-1], -1, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True).clamp(min=2.0 ** -126)
+    sc = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+    q = minifloat(xb / sc, ebits, mbits, bias, vmax) * sc
+    q = q.reshape(*xm.shape[:-1], -1)[..., :C]
+    return q.movedim(-1, dim)
+
+
+def mx4(x, dim, mode='ocp', lo_of=None):
+    """fp4 e2m1 block quantiser as the HIP staging code does it.  mode 'ocp': scale 2^(floor(log2 amax)-2), saturating;
+    'noclip': scale 2^ceil(log2(amax/6)).  lo_of: derive the scale from the block max of THAT tensor (the fp16-rounded
+    operand) as 2^(max(E-11,-25)-2) instead of from x's own max."""
+    xm = x.movedim(dim, -1)
+    C = xm.shape[-1]
+    pad = (-C) % 32
+    if pad:
+        xm = F.pad(xm, (0, pad))
+    xb = xm.reshape(*xm.shape[:-1], -1, 32)
+    if lo_of is not None:
+        am = lo_of.movedim(dim, -1)
+        if pad:
+            am = F.pad(am, (0, pad))
+        amax = am.reshape(*am.shape[:-1], -1, 32).abs().amax(dim=-1, keepdim=True).clamp(min=2.0 ** -126)
+        E = torch.floor(torch.log2(amax))
+        sc = torch.exp2(torch.clamp(E - 11, min=-25.0) - 2)
+    else:
+        amax = xb.abs().amax(dim=-1, keepdim=True).clamp(min=2.0 ** -126)
+        if mode == 'ocp':
+            sc = torch.exp2(torch.floor(torch.log2(amax)) - 2)
+        else:
+            sc = torch.exp2(torch.ceil(torch.log2(amax / 6.0)))
+    q = minifloat(xb / sc, 2, 1, 1, 6.0) * sc
+    q = q.reshape(*xm.shape[:-1], -1)[..., :C]
+    return q.movedim(-1, dim)
+
+
+def make_conv(scheme):
+    def conv(x, w, b=None, stride=1, padding=0, *a, **k):
+        if x.shape[1] == 1:                      # the stem runs on the exact-fp32 MFMA
+            return _conv(x, w, b, stride, padding, *a, **k)
+        c = lambda xx, ww: _conv(xx, ww, None, stride, padding, *a, **k)
+        if scheme == 'bf16':
+            y = c(bf16(x), bf16(w))
+        elif scheme == 'fp16':
+            y = c(fp16(x), fp16(w))
+        elif scheme == 'fp16_a_only':
+            y = c(fp16(x), w)
+        elif scheme == 'bf16x3':
+            xh, wh = bf16(x), bf16(w)
+            xl, wl = bf16(x - xh), bf16(w - wh)
+            y = c(xh, wh) + c(xl, wh) + c(xh, wl)
+        elif scheme.startswith('fp16+'):
+            kind = scheme.split('+')[1]           # bf8 / fp8 (unscaled, 2^12 prescale) or mx kinds
+            xh, wh = fp16(x), fp16(w)
+            xl, wl = x - xh, w - wh
+            if kind in ('bf8', 'fp8'):
+                q = bf8 if kind == 'bf8' else fp8
+                s = 2.0 ** 12
+                y = c(xh, wh) + c(q(xl * s) / s, q(w)) + c(q(x), q(wl * s) / s)
+            else:
+                kind = kind[2:]                   # mxfp6 -> fp6 ...
+                y = c(xh, wh) + c(mx(xl, 1, kind), mx(w, 1, kind)) + c(mx(x, 1, kind), mx(wl, 1, kind))
+        elif scheme.startswith('f16f4'):
+            # f16f4[-noclip][-dlo]: activations and weights fp16 hi + fp4 lo / fp4 copy
+            mode = 'noclip' if 'noclip' in scheme else 'ocp'
+            xc = x.clamp(-65504.0, 65504.0)
+            xh, wh = fp16(xc), fp16(w)
+            xl, wl = x - xh, w - wh
+            xl4 = mx4(xl, 1, mode, lo_of=xh if 'dlo' in scheme else None)
+            y = c(xh, wh) + c(xl4, mx4(w, 1, mode)) + c(mx4(x, 1, mode), mx4(wl, 1, mode))
+        elif scheme.startswith('bf16+'):
+            kind = scheme.split('+')[1][2:]
+            xh, wh = bf16(x), bf16(w)
+            xl, wl = x - xh, w - wh
+            y = c(xh, wh) + c(mx(xl, 1, kind), mx(w, 1, kind)) + c(mx(x, 1, kind), mx(wl, 1, kind))
+        else:
+            raise ValueError(scheme)
+        return y if b is None else y + b.reshape(1, -1, 1, 1)
+    return conv
+
+
+def main():
+    gd = ROOT / 'tests' / 'golden'
+    size = 64
+    if sys.argv[1:] and sys.argv[1].isdigit():
+        size = int(sys.argv.pop(1))
+    g = np.load(gd / f'eps_d64_s{size}.npz')
+    shapes = {k: tuple(v) for k, v in json.loads((gd / 'unet_d64_state_dict_keys.json').read_text()).items()}
+    w = synth_state_dict(shapes, 0)
+    x_t, t = torch.from_numpy(g['x_t']), torch.from_numpy(g['t'])
+    ref = O.unet_forward(w, x_t, t)
+    schemes = sys.argv[1:] or ['bf16', 'fp16', 'fp16_a_only', 'bf16x3', 'fp16+bf8', 'fp16+fp8', 'fp16+mxfp8', 'fp16+mxbf8',
+                               'fp16+mxfp6', 'fp16+mxbf6', 'fp16+mxfp4', 'bf16+mxfp8', 'bf16+mxfp6']
+    for s in schemes:
+        F.conv2d = make_conv(s)
+        try:
+            eps = O.unet_forward(w, x_t, t)
+        finally:
+            F.conv2d = _conv
+        print(f'{s:14s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
