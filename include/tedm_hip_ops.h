@@ -27,6 +27,12 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
                    const float* add, const float* add_a, const float* add_b,
                    float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream);
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
+/* Tuning harness: the same conv, weights packed once, 2 warm-up launches, then `iters` launches bracketed by HIP events on
+ * `stream`; *ms_per_launch = their mean duration. */
+int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B, int H, int W,
+                         const float* weight_oihw, const float* bias, int Cout, int k, int stride, int upsample,
+                         const float* gn_a, const float* gn_b, const float* add, float* out, float* stats, int stats_mode,
+                         int prec, int iters, float* ms_per_launch, void* stream);
 
 /* Backward of one nn.Conv2d (same geometries as tedm_op_conv2d; `upsample` = the forward conv read the
  * nearest-x2 upsampled x).  dy (B,Ho,Wo,Cout), x (B,H,W,Cin) NHWC; dx (B,H,W,Cin) and/or dw (Cout,Cin,k,k)

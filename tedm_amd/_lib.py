@@ -67,6 +67,8 @@ _SIGNATURES = {
                                   C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                   C.POINTER(C.c_int), C.c_int, _P]),
     'tedm_op_conv2d_stats_entries': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_op_conv2d_bench': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     'tedm_op_conv2d_backward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _P, _P, C.c_int, _P]),
     'tedm_op_gn_silu_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_longlong, C.c_int, C.c_int,

@@ -25,7 +25,8 @@ struct TileSel { int wm, wn, mt; };
 //   id 2 "wide4"  : 1x4 waves, 4 M-tiles -> 128 px x 128 cout
 // stride-2 convs use half the rows (the halo doubles).
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
-int g_tile_wide = 2;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v))
+int g_tile_wide = 3;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v)); 2x4 waves: two wave rows share
+                          // every weight fragment (half the L2 weight traffic per FLOP of the 1x4 tile)
 int g_tile_narrow = 1;
 // g_tile_narrow: tile id used when Cout < 128 (tedm_set_tuning("conv_tile_narrow", v))
 

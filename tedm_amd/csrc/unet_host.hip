@@ -1046,6 +1046,46 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d failed (%d)", rc);
 }
 
+// ---- tuning harness: time `iters` launches of one conv (weights packed once, HIP events on `stream`) ----
+int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
+                         const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
+                         const float* add, float* out, float* stats, int stats_mode, int prec, int iters, float* ms_per_launch,
+                         void* stream) {
+    g_err[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = C1 + C2;
+    if (!x1 || !weight_oihw || !out || Cin % 16 || iters < 1 || !ms_per_launch) return fail(TEDM_EINVAL, "bad argument");
+    int Ho, Wo;
+    if (k == 4 && stride == 2) { Ho = H / 2; Wo = W / 2; }
+    else if ((k == 3 || k == 1) && stride == 1) { Ho = upsample ? 2 * H : H; Wo = upsample ? 2 * W : W; }
+    else return fail(TEDM_EINVAL, "unsupported conv geometry k=%d stride=%d", k, stride);
+    void* wpk = nullptr;
+    if (hipMalloc(&wpk, conv_packed_bytes(Cout, Cin, k * k)) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
+    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rc == TEDM_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = TEDM_EHIP;
+    if (rc == TEDM_OK) {
+        ConvArgs a{};
+        a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+        a.wpk = wpk; a.bias = bias;
+        int pro = PRO_NONE;
+        if (gn_a) { pro = PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        a.out = out; a.add = add; a.stats = stats; a.stats_mode = stats ? stats_mode : STATS_NONE; a.prec = prec;
+        for (int i = 0; i < 2 && rc == TEDM_OK; ++i) rc = conv_launch(a, k, stride, upsample, pro, st);
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == TEDM_OK; ++i) rc = conv_launch(a, k, stride, upsample, pro, st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = TEDM_EHIP;
+        float ms = 0.f;
+        if (rc == TEDM_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *ms_per_launch = ms / iters;
+    }
+    (void)hipStreamSynchronize(st);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(wpk);
+    return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d_bench failed (%d)", rc);
+}
+
 // ---- op-level entry point (tests): the three fused linear-attention sweeps + their finalizers ----
 int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* lnstats, const float* wqkv_oihw,
                           int B, long long hw, float* kmax_out, float* ctx_out, float* o_out, int prec, void* stream) {

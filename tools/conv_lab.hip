@@ -1,0 +1,138 @@
+// conv_lab.hip -- diagnostic (not product): A/B timing of conv_igemm_kernel VARIANTS in one process on one device
+// (cdna guide rule 24).  Each variant is the product kernel source (tedm_amd/csrc/conv_igemm.inc) included under its own
+// namespace with different CONV_LAB_* switches; weights are packed by the product pack kernels, inputs are random.
+// No correctness check here (tests/ does that for the variant that ships) -- this measures.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Itedm_amd/csrc tools/conv_lab.hip -o tools/build/conv_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#include <math.h>
+#include <type_traits>
+#define CONV_NO_LAUNCHERS
+#define CONV_PREC 3
+#include "common.h"
+#include "../../include/tedm_hip.h"
+#include "pack.hip"
+
+#define VARIANT(NS, ...) namespace NS { __VA_ARGS__ }
+namespace v0 {
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_PD
+#undef CONV_LAB_SPREAD
+namespace v1 {
+#define CONV_LAB_SPREAD 0
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_PD
+#undef CONV_LAB_SPREAD
+namespace v2 {
+#define CONV_LAB_PD 0
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_PD
+#undef CONV_LAB_SPREAD
+namespace v3 {
+#define CONV_LAB_PD 0
+#define CONV_LAB_SPREAD 0
+#include "conv_igemm.inc"
+}
+
+static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int C1, C2, Cout, S, gn; };
+
+template <typename K>
+static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int grid, int iters) {
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+// one (variant, tile) measurement of a 3x3 stride-1 conv
+#define RUN(NS, WM, WN, MT, PRO, LABEL)                                                                              \
+    do {                                                                                                             \
+        using G = NS::Geo<3, 3, 1, WM, MT, 2, 2, 3, WM * WN * 64>;                                                   \
+        ConvArgs b = a;                                                                                              \
+        const int TR = WM * MT;                                                                                      \
+        b.tiles_y = (b.Ho + TR - 1) / TR; b.tiles_x = (b.Wo + 31) / 32;                                              \
+        b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = 1; b.xcd_order = 1;                                       \
+        const int grid = b.B * b.tiles_x * b.tiles_y * b.ny;                                                         \
+        const float ms = time_kernel(NS::conv_igemm_kernel<3, 3, 1, 1, 0, WM, WN, MT, 2, 2, PRO, 3>, b, WM * WN * 64, \
+                                     (size_t)G::LDS, grid, iters);                                                   \
+        res.push_back({LABEL, ms});                                                                                  \
+    } while (0)
+
+struct Res { const char* label; float ms; };
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 10;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 3;
+    const Shape shapes[] = {
+        {"l0_64_64", 64, 0, 64, 256, 0}, {"l0_64_64_gn", 64, 0, 64, 256, 1}, {"l0_128_64", 64, 64, 64, 256, 0},
+        {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l3_768_512", 512, 256, 512, 32, 0},
+    };
+    const int B = 32;
+    for (const Shape& sh : shapes) {
+        const int Cin = sh.C1 + sh.C2;
+        const size_t n1 = (size_t)B * sh.S * sh.S * sh.C1, n2 = (size_t)B * sh.S * sh.S * sh.C2, no = (size_t)B * sh.S * sh.S * sh.Cout;
+        float *x1, *x2 = nullptr, *out, *w, *bias, *ga, *gb, *stats;
+        void* wpk;
+        CK(hipMalloc(&x1, n1 * 4)); if (n2) CK(hipMalloc(&x2, n2 * 4)); CK(hipMalloc(&out, no * 4));
+        CK(hipMalloc(&w, (size_t)sh.Cout * Cin * 9 * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
+        CK(hipMalloc(&ga, (size_t)B * Cin * 4)); CK(hipMalloc(&gb, (size_t)B * Cin * 4));
+        CK(hipMalloc(&stats, (size_t)B * 4096 * sh.Cout * 2 * 4));
+        CK(hipMalloc(&wpk, conv_packed_bytes_lab(sh.Cout, Cin, 9)));
+        {   // random fill on the host (normal-ish via sum of uniforms)
+            std::vector<float> h(std::max({n1, n2, (size_t)sh.Cout * Cin * 9}));
+            auto fill = [&](float* d, size_t n, float scale) {
+                for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() + rand() + rand() + rand()) / (float)RAND_MAX - 2.f) * 1.7f;
+                CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+            };
+            fill(x1, n1, 1.f); if (n2) fill(x2, n2, 1.f);
+            fill(w, (size_t)sh.Cout * Cin * 9, 1.f / sqrtf(Cin * 9.f)); fill(bias, sh.Cout, 0.1f);
+            fill(ga, (size_t)B * Cin, 0.1f); fill(gb, (size_t)B * Cin, 0.1f);
+        }
+        if (pack_conv_weights(w, sh.Cout, Cin, 3, 3, wpk, ENC_F16F4, 0) != 0) { printf("pack failed\n"); return 1; }
+        ConvArgs a{};
+        a.x1 = x1; a.C1 = sh.C1; a.x2 = x2; a.C2 = sh.C2; a.B = B; a.H = sh.S; a.W = sh.S; a.Ho = sh.S; a.Wo = sh.S; a.Cout = sh.Cout;
+        a.wpk = wpk; a.bias = bias; a.out = out; a.stats = stats; a.stats_mode = STATS_SUMSQ; a.nk16 = Cin / 16; a.prec = 3;
+        if (sh.gn) { a.pro_a = ga; a.pro_b = gb; }
+        const double flops = 2.0 * B * sh.S * sh.S * sh.Cout * Cin * 9;
+        std::vector<std::vector<Res>> all;
+        for (int r = 0; r < rounds; ++r) {
+            std::vector<Res> res;
+            if (sh.Cout < 128) {
+                if (sh.gn) { RUN(v0, 2, 2, 4, 1, "v0 spread,PD1  narrow"); RUN(v1, 2, 2, 4, 1, "v1 single,PD1  narrow"); RUN(v2, 2, 2, 4, 1, "v2 spread,PD0  narrow"); RUN(v3, 2, 2, 4, 1, "v3 single,PD0  narrow"); }
+                else       { RUN(v0, 2, 2, 4, 0, "v0 spread,PD1  narrow"); RUN(v1, 2, 2, 4, 0, "v1 single,PD1  narrow"); RUN(v2, 2, 2, 4, 0, "v2 spread,PD0  narrow"); RUN(v3, 2, 2, 4, 0, "v3 single,PD0  narrow"); }
+            } else {
+                if (sh.gn) { RUN(v0, 1, 4, 4, 1, "v0 spread,PD1  wide4"); RUN(v1, 1, 4, 4, 1, "v1 single,PD1  wide4"); RUN(v2, 1, 4, 4, 1, "v2 spread,PD0  wide4"); RUN(v3, 1, 4, 4, 1, "v3 single,PD0  wide4");
+                             RUN(v0, 2, 4, 4, 1, "v0 spread,PD1  wide8w"); RUN(v2, 2, 4, 4, 1, "v2 spread,PD0  wide8w"); RUN(v0, 1, 4, 8, 1, "v0 spread,PD1  wide8"); RUN(v1, 1, 4, 8, 1, "v1 single,PD1  wide8"); }
+                else       { RUN(v0, 1, 4, 4, 0, "v0 spread,PD1  wide4"); RUN(v1, 1, 4, 4, 0, "v1 single,PD1  wide4"); RUN(v2, 1, 4, 4, 0, "v2 spread,PD0  wide4"); RUN(v3, 1, 4, 4, 0, "v3 single,PD0  wide4");
+                             RUN(v0, 2, 4, 4, 0, "v0 spread,PD1  wide8w"); RUN(v2, 2, 4, 4, 0, "v2 spread,PD0  wide8w"); RUN(v0, 1, 4, 8, 0, "v0 spread,PD1  wide8"); RUN(v1, 1, 4, 8, 0, "v1 single,PD1  wide8"); }
+            }
+            all.push_back(res);
+        }
+        for (size_t i = 0; i < all[0].size(); ++i) {
+            std::vector<float> t;
+            for (auto& r : all) t.push_back(r[i].ms);
+            std::sort(t.begin(), t.end());
+            printf("%-14s %-24s min %7.1f us  med %7.1f us  %7.1f TF/s\n", sh.name, all[0][i].label, t[0] * 1e3, t[t.size() / 2] * 1e3,
+                   flops / (t[t.size() / 2] * 1e-3) / 1e12);
+        }
+        fflush(stdout);
+        hipFree(x1); if (x2) hipFree(x2); hipFree(out); hipFree(w); hipFree(bias); hipFree(ga); hipFree(gb); hipFree(stats); hipFree(wpk);
+    }
+    return 0;
+}
