@@ -12,7 +12,7 @@ int conv_launch_prec3(const ConvArgs& a, int KH, int stride, int ups, int pro, i
 
 int g_conv_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
 int g_conv_solo = 0;           // tedm_set_tuning("conv_solo", 1): pad the LDS request so that workgroups do not share a CU (diagnostic)
-int g_conv_tpw_max = 1;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
+int g_conv_tpw_max = 4;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
 int g_conv_xcd_order = 1;      // 1: cout-tile groups of one input tile share an XCD (tedm_set_tuning("conv_xcd_order", v))
 
 namespace {

@@ -22,25 +22,26 @@
 namespace v0 {
 #include "conv_igemm.inc"
 }
-#undef CONV_LAB_PD
-#undef CONV_LAB_SPREAD
-namespace v1 {
-#define CONV_LAB_SPREAD 0
+namespace a1 {
+#define CONV_LAB_ABL 1
 #include "conv_igemm.inc"
 }
-#undef CONV_LAB_PD
-#undef CONV_LAB_SPREAD
-namespace v2 {
-#define CONV_LAB_PD 0
+#undef CONV_LAB_ABL
+namespace a2 {
+#define CONV_LAB_ABL 2
 #include "conv_igemm.inc"
 }
-#undef CONV_LAB_PD
-#undef CONV_LAB_SPREAD
-namespace v3 {
-#define CONV_LAB_PD 0
-#define CONV_LAB_SPREAD 0
+#undef CONV_LAB_ABL
+namespace a4 {
+#define CONV_LAB_ABL 4
 #include "conv_igemm.inc"
 }
+#undef CONV_LAB_ABL
+namespace a7 {
+#define CONV_LAB_ABL 7
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_ABL
 
 static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -61,14 +62,15 @@ static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int
 }
 
 // one (variant, tile) measurement of a 3x3 stride-1 conv
-#define RUN(NS, WM, WN, MT, PRO, LABEL)                                                                              \
+#define RUN(NS, WM, WN, MT, PRO, LABEL) RUNT(NS, WM, WN, MT, PRO, 1, LABEL)
+#define RUNT(NS, WM, WN, MT, PRO, TPW, LABEL)                                                                              \
     do {                                                                                                             \
         using G = NS::Geo<3, 3, 1, WM, MT, 2, 2, 3, WM * WN * 64>;                                                   \
         ConvArgs b = a;                                                                                              \
         const int TR = WM * MT;                                                                                      \
         b.tiles_y = (b.Ho + TR - 1) / TR; b.tiles_x = (b.Wo + 31) / 32;                                              \
-        b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = 1; b.xcd_order = 1;                                       \
-        const int grid = b.B * b.tiles_x * b.tiles_y * b.ny;                                                         \
+        b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = TPW; b.xcd_order = 1;                                     \
+        const int grid = ((b.B * b.tiles_x * b.tiles_y + TPW - 1) / TPW) * b.ny;                                                  \
         const float ms = time_kernel(NS::conv_igemm_kernel<3, 3, 1, 1, 0, WM, WN, MT, 2, 2, PRO, 3>, b, WM * WN * 64, \
                                      (size_t)G::LDS, grid, iters);                                                   \
         res.push_back({LABEL, ms});                                                                                  \
@@ -114,13 +116,11 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
             if (sh.Cout < 128) {
-                if (sh.gn) { RUN(v0, 2, 2, 4, 1, "v0 spread,PD1  narrow"); RUN(v1, 2, 2, 4, 1, "v1 single,PD1  narrow"); RUN(v2, 2, 2, 4, 1, "v2 spread,PD0  narrow"); RUN(v3, 2, 2, 4, 1, "v3 single,PD0  narrow"); }
-                else       { RUN(v0, 2, 2, 4, 0, "v0 spread,PD1  narrow"); RUN(v1, 2, 2, 4, 0, "v1 single,PD1  narrow"); RUN(v2, 2, 2, 4, 0, "v2 spread,PD0  narrow"); RUN(v3, 2, 2, 4, 0, "v3 single,PD0  narrow"); }
+                if (sh.gn) { RUN(v0, 2, 2, 4, 1, "v0 narrow tpw1"); RUNT(v0, 2, 2, 4, 1, 2, "v0 narrow tpw2"); RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow tpw4"); RUNT(v0, 2, 2, 4, 1, 8, "v0 narrow tpw8"); RUN(v0, 4, 2, 4, 1, "v0 4x2x4 16rows"); RUNT(v0, 4, 2, 4, 1, 4, "v0 4x2x4 tpw4"); }
+                else       { RUN(v0, 2, 2, 4, 0, "v0 narrow tpw1"); RUNT(v0, 2, 2, 4, 0, 2, "v0 narrow tpw2"); RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow tpw4"); RUNT(v0, 2, 2, 4, 0, 8, "v0 narrow tpw8"); RUN(v0, 4, 2, 4, 0, "v0 4x2x4 16rows"); RUNT(v0, 4, 2, 4, 0, 4, "v0 4x2x4 tpw4"); }
             } else {
-                if (sh.gn) { RUN(v0, 1, 4, 4, 1, "v0 spread,PD1  wide4"); RUN(v1, 1, 4, 4, 1, "v1 single,PD1  wide4"); RUN(v2, 1, 4, 4, 1, "v2 spread,PD0  wide4"); RUN(v3, 1, 4, 4, 1, "v3 single,PD0  wide4");
-                             RUN(v0, 2, 4, 4, 1, "v0 spread,PD1  wide8w"); RUN(v2, 2, 4, 4, 1, "v2 spread,PD0  wide8w"); RUN(v0, 1, 4, 8, 1, "v0 spread,PD1  wide8"); RUN(v1, 1, 4, 8, 1, "v1 single,PD1  wide8"); }
-                else       { RUN(v0, 1, 4, 4, 0, "v0 spread,PD1  wide4"); RUN(v1, 1, 4, 4, 0, "v1 single,PD1  wide4"); RUN(v2, 1, 4, 4, 0, "v2 spread,PD0  wide4"); RUN(v3, 1, 4, 4, 0, "v3 single,PD0  wide4");
-                             RUN(v0, 2, 4, 4, 0, "v0 spread,PD1  wide8w"); RUN(v2, 2, 4, 4, 0, "v2 spread,PD0  wide8w"); RUN(v0, 1, 4, 8, 0, "v0 spread,PD1  wide8"); RUN(v1, 1, 4, 8, 0, "v1 single,PD1  wide8"); }
+                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 wide8w"); RUNT(v0, 2, 4, 4, 1, 2, "v0 wide8w tpw2"); RUN(v0, 2, 4, 8, 1, "v0 2x4x8 wide16"); RUNT(v0, 2, 4, 8, 1, 2, "v0 2x4x8 tpw2"); RUN(v0, 4, 2, 4, 1, "v0 4x2x4 16r x64"); }
+                else       { RUN(v0, 2, 4, 4, 0, "v0 wide8w"); RUNT(v0, 2, 4, 4, 0, 2, "v0 wide8w tpw2"); RUN(v0, 2, 4, 8, 0, "v0 2x4x8 wide16"); RUNT(v0, 2, 4, 8, 0, 2, "v0 2x4x8 tpw2"); RUN(v0, 4, 2, 4, 0, "v0 4x2x4 16r x64"); }
             }
             all.push_back(res);
         }
