@@ -146,6 +146,12 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
 /* Backward of the recorded forward.  d_eps: (B, out_dim, H, W) fp32 = d loss / d eps.  Must be given the
  * same workspace; consumes the tape (one backward per forward_train). */
 int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream);
+/* The handle keeps ONE tape.  Every tedm_unet_forward_train bumps a generation counter (tedm_unet_tape_generation returns
+ * the generation of the tape now held); tedm_unet_backward_gen fails with TEDM_ESTATE ("tape overwritten by a later
+ * forward") when `generation` is not the tape's -- use it whenever two forwards can be outstanding (autograd). */
+long long tedm_unet_tape_generation(const tedm_unet* h);
+int tedm_unet_backward_gen(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream,
+                           long long generation);
 /* DiffusionModel.train_step's loss (models/diffusion_model.py:138-143):
  *   loss = mean_b( mean_chw |eps - target| * p2w[t_b] ),  grad = d loss / d eps  (grad may be NULL).
  * scratch: B*64 floats; loss: 1 float; all device pointers. */

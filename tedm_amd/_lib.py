@@ -46,6 +46,8 @@ _SIGNATURES = {
     'tedm_unet_train_workspace_bytes': (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     'tedm_unet_forward_train': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    'tedm_unet_backward_gen': (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_longlong]),
+    'tedm_unet_tape_generation': (C.c_longlong, [_P]),
     'tedm_l1_loss': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, _P, _P, _P, _P]),
     'tedm_unet_module_channels': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tedm_unet_module_workspace_bytes': (C.c_size_t, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int]),

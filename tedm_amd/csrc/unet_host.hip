@@ -78,7 +78,13 @@ struct Arena {
         }
         if (off == (size_t)-1) { off = top; top += n; if (top > peak) peak = top; }
         live[off] = n;
-        if (!dry && off + n > cap) oom = true;
+        if (!dry && (off + n > cap || n > cap)) {
+            // never hand out an address outside the caller's workspace: flag the overflow (every entry point checks `oom`
+            // and fails) and park the allocation at the base so that whatever is launched before the check stays in bounds
+            oom = true;
+            live.erase(off);
+            return (float*)base;
+        }
         return (float*)(base + off);
     }
     void release(const void* p) {
@@ -112,6 +118,7 @@ struct AttnTape { const float* x = nullptr; int H = 0, W = 0;
 struct TailTape { const float* in = nullptr; float* out = nullptr; int H = 0, W = 0; };
 struct Tape {
     int B = 0, H = 0, W = 0, prec = 0; bool film = false, valid = false;
+    long long gen = 0;      // which forward_train recorded this tape (tedm_unet_tape_generation)
     const float* x_in = nullptr; float* r = nullptr; float* msave = nullptr; float* st = nullptr; float* filmbuf = nullptr;
     std::vector<ResTape> d1, d2, u1, u2; std::vector<AttnTape> da, ua; std::vector<TailTape> dt, ut;
     ResTape m1, m2, fin; AttnTape ma;
@@ -186,6 +193,7 @@ struct tedm_unet {
     std::vector<float*> grads;         // per-parameter gradient buffers (tedm_unet_set_grad), same order as params
     bool packed_bwd = false;
     Tape tape;
+    long long tape_gen = 0; // bumped by every tedm_unet_forward_train
 
     ~tedm_unet() {
         for (ConvW* c : convs) {
@@ -659,16 +667,29 @@ int tedm_unet_set_precision(tedm_unet* h, int prec) {
     return TEDM_OK;
 }
 
-size_t tedm_unet_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags) {
-    g_err[0] = 0;
-    if (!h || check_shape(h, B, H, W) != TEDM_OK) return 0;
+namespace {
+// Dry run of the forward's allocation sequence.  `ext_taps`: bit i set = the caller provides feat_out[i], so that tap is
+// NOT taken from the arena -- the sizing replays exactly the sequence the real call makes (a first-fit free list is not
+// monotone under removed allocations).
+size_t forward_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags, unsigned ext_taps) {
     Arena A;
     A.dry = true; A.keep = flags & TEDM_FWD_TRACE;
     Fwd f{const_cast<tedm_unet*>(h), &A, nullptr, true, B, 0, true, nullptr, false};
     static const float dummy_t = 0.f;
+    static float ext_marker;                                 // never dereferenced in a dry run
     float* taps[TEDM_MAX_LEVELS] = {nullptr};
+    for (int i = 0; i < TEDM_MAX_LEVELS; ++i) if (ext_taps & (1u << i)) taps[i] = &ext_marker;
     if (f.run(nullptr, &dummy_t, H, W, nullptr, taps, flags) != TEDM_OK) return 0;
     return A.peak + 256;
+}
+}  // namespace
+
+size_t tedm_unet_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags) {
+    g_err[0] = 0;
+    if (!h || check_shape(h, B, H, W) != TEDM_OK) return 0;
+    // the caller may or may not pass tap buffers later: report the larger of the two sequences
+    const size_t a = forward_workspace_bytes(h, B, H, W, flags, 0u), b = forward_workspace_bytes(h, B, H, W, flags, ~0u);
+    return a > b ? a : b;
 }
 
 int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H, int W, float* eps_out,
@@ -689,8 +710,10 @@ int tedm_unet_forward(tedm_unet* h, const float* x, const float* t, int B, int H
     A.dry = false; A.keep = flags & TEDM_FWD_TRACE;
     h->trace.clear();
     Fwd f{h, &A, (hipStream_t)stream, false, B, prec, t != nullptr, nullptr, (bool)(flags & TEDM_FWD_TRACE)};
-    // The arena hands out addresses before checking capacity, so size-check with a dry run first.
-    const size_t need = tedm_unet_workspace_bytes(h, B, H, W, flags);
+    // Size-check with a dry run of exactly this call's allocation sequence (which taps are external) before any launch.
+    unsigned ext = 0;
+    for (int i = 0; feat_out && i < h->nres; ++i) if (feat_out[i]) ext |= 1u << i;
+    const size_t need = forward_workspace_bytes(h, B, H, W, flags, ext);
     if (need == 0) return fail(TEDM_EINVAL, "workspace sizing failed");
     if (workspace_bytes < need) return fail(TEDM_ENOMEM, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     const int rc = f.run(x, t, H, W, eps_out, feat_out, flags);
@@ -765,6 +788,7 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
     A.cap = workspace_bytes - (mis ? 256 - mis : 0);
     A.dry = false;
     h->tape = Tape();
+    h->tape.gen = ++h->tape_gen;
     hipStream_t st = (hipStream_t)stream;
     Train tr{h, &A, st, false, B, prec, &h->tape, Fwd{h, &A, st, false, B, prec, t != nullptr, nullptr, false}};
     const int rc = tr.forward(x, t, H, W, eps_out);
@@ -775,10 +799,20 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
     return TEDM_OK;
 }
 
+long long tedm_unet_tape_generation(const tedm_unet* h) { return h ? h->tape_gen : 0; }
+
 int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream) {
+    return tedm_unet_backward_gen(h, d_eps, workspace, workspace_bytes, stream, 0);
+}
+
+int tedm_unet_backward_gen(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream,
+                           long long generation) {
     g_err[0] = 0;
     if (!h || !d_eps || !workspace) return fail(TEDM_EINVAL, "null argument");
     Tape& T = h->tape;
+    if (generation && generation != T.gen)
+        return fail(TEDM_ESTATE, "tape overwritten by a later forward: this backward belongs to forward_train #%lld, the handle holds #%lld "
+                                 "(one tape per Unet: run backward before the next training forward)", generation, T.gen);
     if (!T.valid) return fail(TEDM_ESTATE, "no training tape: call tedm_unet_forward_train first");
     if (!h->packed_bwd) return fail(TEDM_ESTATE, "tedm_unet_pack_backward() has not been called since parameters were (re)bound");
     const size_t mis = (size_t)((uintptr_t)workspace & 255);

@@ -29,7 +29,9 @@ class DatasetDM(nn.Module):
             if getattr(args, 'verbose', False):
                 print(f'No model found at {path}. Please load model!')
         else:                                                                  # :38-43 (Namespace pickled inside)
-            ckpt = torch.load(path, map_location=torch.device(getattr(args, 'device', 'cpu')), weights_only=False)
+            from .checkpoint import load_checkpoint
+            ckpt = load_checkpoint(path, map_location=torch.device(getattr(args, 'device', 'cpu')),
+                                   allow_unsafe=bool(getattr(args, 'allow_unsafe_checkpoint', False)))
             self.diffusion_model = DiffusionModel(ckpt['config'])
             self.diffusion_model.load_state_dict(ckpt['model_state_dict'])
         self.diffusion_model.eval()

@@ -40,11 +40,14 @@ def save(model, optimizer, config, path, step) -> None:
 
 
 def load(new_config, path, model_cls=None) -> Tuple[torch.nn.Module, torch.optim.Optimizer, int]:
-    """train_CXR14.py:105-114: rebuild the model from the checkpoint's own config (a pickled Namespace, hence
-    weights_only=False), restore model + Adam state, return (model, optimizer, step)."""
+    """train_CXR14.py:105-114: rebuild the model from the checkpoint's own config (a pickled Namespace: loaded through
+    `checkpoint.load_checkpoint`, weights_only=True with Namespace / PosixPath allow-listed), restore model + Adam state,
+    return (model, optimizer, step)."""
     if model_cls is None:
         from .diffusion import DiffusionModel as model_cls
-    ckpt = torch.load(path, map_location=torch.device(new_config.device), weights_only=False)
+    from .checkpoint import load_checkpoint
+    ckpt = load_checkpoint(path, map_location=torch.device(new_config.device),
+                           allow_unsafe=bool(getattr(new_config, 'allow_unsafe_checkpoint', False)))
     old = ckpt['config']
     for k, v in vars(new_config).items():                        # compare_configs (trainers/utils.py): report only
         if k in vars(old) and vars(old)[k] != v and k not in ('resume_path', 'log_dir', 'device'):

@@ -166,11 +166,13 @@ class _UnetTrainFn(torch.autograd.Function):
     def forward(ctx, unet, x, timestep, names, *params):
         ctx.unet, ctx.names = unet, names
         ctx.mask = [p.requires_grad for p in params]
-        return unet.native_forward_train(x, timestep)
+        eps = unet.native_forward_train(x, timestep)
+        ctx.generation = unet.tape_generation()         # the handle keeps ONE tape: a later forward overwrites it
+        return eps
 
     @staticmethod
     def backward(ctx, d_eps):
-        views = ctx.unet.native_backward(d_eps)
+        views = ctx.unet.native_backward(d_eps, generation=ctx.generation)
         grads = [views[k].clone() if m else None for k, m in zip(ctx.names, ctx.mask)]
         return (None, None, None, None, *grads)
 
@@ -239,6 +241,17 @@ class Unet(nn.Module):
                 object.__setattr__(mod, '_owner', (self,))
                 object.__setattr__(mod, '_qualname', name)
         self.last_trace: Dict[str, Tensor] = {}
+
+    def invalidate_packed(self) -> None:
+        """Force the packed (MFMA-fragment) weight copies to be rebuilt at the next forward.
+
+        Repacking is keyed on (data_ptr, _version, dtype) of every parameter, which catches optimizer steps,
+        `load_state_dict` and `.to()`.  In-place edits that bypass autograd's version counter -- `p.data.copy_()`,
+        `p.data.clamp_()`, EMA `p.data.lerp_()`, `set_()`, external kernels writing through the pointer -- do NOT bump
+        `_version`: call this after them, or the forward mixes stale packed conv weights with the live biases / norm
+        parameters it reads through the bound pointers."""
+        self._fingerprint = None
+        self._bwd_fingerprint = None
 
     # -- native handle ---------------------------------------------------------------------
     def __del__(self):
@@ -460,15 +473,21 @@ class Unet(nn.Module):
                 'tedm_unet_forward_train')
         return eps
 
-    def native_backward(self, d_eps: Tensor) -> Dict[str, Tensor]:
-        """Backward of the last `native_forward_train`; overwrites `grad_flat` and returns its views."""
+    def tape_generation(self) -> int:
+        """Generation of the training tape the native handle holds (bumped by every `native_forward_train`)."""
+        return int(_lib.lib().tedm_unet_tape_generation(self._handle)) if self._handle is not None else 0
+
+    def native_backward(self, d_eps: Tensor, generation: int = 0) -> Dict[str, Tensor]:
+        """Backward of the last `native_forward_train`; overwrites `grad_flat` and returns its views.  `generation`
+        (from `tape_generation()` right after the forward) makes the call fail loudly -- 'tape overwritten by a later
+        forward' -- when another training forward ran in between (the handle keeps one tape)."""
         L = _lib.lib()
         dev = d_eps.device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             g = d_eps.detach().float().contiguous()
-            _lib.check(L.tedm_unet_backward(self._handle, g.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(),
-                                            stream), 'tedm_unet_backward')
+            _lib.check(L.tedm_unet_backward_gen(self._handle, g.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(),
+                                                stream, int(generation)), 'tedm_unet_backward')
         return self._grad_views
 
     def _read_trace(self) -> Dict[str, Tensor]:

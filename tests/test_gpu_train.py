@@ -91,6 +91,77 @@ def test_backward_is_deterministic_and_needs_forward(dev):
         m.native_backward(R)
 
 
+def test_backward_of_an_overwritten_tape_fails_loudly(dev):
+    """The handle keeps ONE tape: fwd(A), fwd(B), loss(A).backward() must raise ('tape overwritten by a later forward'),
+    not silently return B's gradients for A."""
+    from tedm_amd import Unet, load_synth_weights, _lib
+    m = Unet(32)
+    load_synth_weights(m, seed=4)
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    xa, xb = torch.randn(2, 1, 32, 32, generator=g).to(dev), torch.randn(2, 1, 32, 32, generator=g).to(dev)
+    t = torch.tensor([10, 500]).to(dev)
+    ea = m(xa, t)
+    eb = m(xb, t)
+    with pytest.raises(_lib.TedmError, match='tape overwritten by a later forward'):
+        ea.sum().backward()
+    assert all(p.grad is None for p in m.parameters())      # nothing was accumulated from the wrong tape
+    eb.sum().backward()                                     # the newest forward's tape is intact
+    gb = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    m(xb, t).sum().backward()
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, gb[k]), k
+
+
+def test_no_timestep_step_after_a_timestep_step_zeroes_time_mlp_grads(dev):
+    """timestep=None: the time MLP / FiLM projections take no part, so their gradient slices must be ZERO, not the
+    previous step's values."""
+    from tedm_amd import Unet, load_synth_weights
+    m = Unet(32)
+    load_synth_weights(m, seed=6)
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(7)
+    x, R = torch.randn(2, 1, 32, 32, generator=g).to(dev), torch.randn(2, 1, 32, 32, generator=g).to(dev)
+    m.native_forward_train(x, torch.tensor([5, 700]).to(dev))
+    views = m.native_backward(R)
+    tkeys = [k for k in views if 'time_mlp' in k]
+    assert tkeys and all(float(views[k].abs().max()) > 0 for k in tkeys)
+    m.native_forward_train(x, None)
+    views = m.native_backward(R)
+    for k in tkeys:
+        assert float(views[k].abs().max()) == 0.0, k
+    assert float(views['downs.0.0.block1.proj.weight'].abs().max()) > 0
+    m.zero_grad(set_to_none=True)                           # autograd path: same contract
+    m(x, None).backward(R)
+    for k, p in m.named_parameters():
+        if 'time_mlp' in k:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+def test_invalidate_packed_after_data_mutation(dev):
+    """`.data` edits do not bump `_version`: the packed conv weights stay stale until `invalidate_packed()`."""
+    from tedm_amd import Unet, load_synth_weights
+    m = Unet(32)
+    load_synth_weights(m, seed=8)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(9)
+    x, t = torch.randn(1, 1, 32, 32, generator=g).to(dev), torch.tensor([100]).to(dev)
+    with torch.no_grad():
+        e0 = m(x, t)
+        m.downs[0][0].block1.proj.weight.data.mul_(0.5)      # no version bump
+        e_stale = m(x, t)
+        m.invalidate_packed()
+        e1 = m(x, t)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['downs.0.0.block1.proj.weight'] *= 2.0            # back to the original values
+        m.load_state_dict(sd)                                # post-hook invalidates by itself
+        e2 = m(x, t)
+    assert torch.equal(e_stale, e0)                          # documents the hazard invalidate_packed() exists for
+    assert not torch.equal(e1, e0)
+    assert torch.allclose(e2, e0, rtol=0, atol=0) or float((e2 - e0).abs().max()) < 1e-6
+
+
 def test_l1_loss_kernel(dev):
     from tedm_amd import DiffusionModel
     dm = DiffusionModel(Namespace(normalize=True, dim=32, p2_loss_weight_gamma=1.0)).to(dev)

@@ -3,6 +3,7 @@ loop order, logging/validation cadence, best-validation checkpoint in the refere
 The HIP compute path is not involved: a stub module with `train_step` stands in for the diffusion model."""
 from argparse import Namespace
 
+import pytest
 import torch
 from torch import nn
 
@@ -79,3 +80,23 @@ def test_reference_format_checkpoint_roundtrip_of_the_diffusion_module(tmp_path)
     assert list(sd) == list(sd2) and len([k for k in sd if k.startswith('model.')]) == 276
     assert len([k for k in sd if not k.startswith('model.')]) == 9
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_checkpoint_loader_refuses_arbitrary_pickles(tmp_path):
+    """Reference checkpoints hold an argparse Namespace (+ PosixPath): loaded with weights_only=True and those two types
+    allow-listed; anything that needs full unpickling is refused unless the caller opts in."""
+    import pathlib
+    from tedm_amd.checkpoint import load_checkpoint
+    good = tmp_path / 'good.pt'
+    torch.save({'model_state_dict': {'w': torch.ones(3)}, 'config': Namespace(dim=64, log_dir=pathlib.Path('/tmp/x')), 'step': 7}, good)
+    ck = load_checkpoint(good)
+    assert ck['step'] == 7 and ck['config'].dim == 64 and torch.equal(ck['model_state_dict']['w'], torch.ones(3))
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ('arbitrary code ran',))
+    bad = tmp_path / 'bad.pt'
+    torch.save({'config': Evil()}, bad)
+    with pytest.raises(RuntimeError, match='weights_only'):
+        load_checkpoint(bad)
+    assert load_checkpoint(bad, allow_unsafe=True) is not None     # explicit opt-in only
