@@ -223,7 +223,8 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC', 'bf16x3'), choices=['bf16x3', 'bf16', 'fp16x2', 'f16f4'])
+    ap.add_argument('--prec', default=os.environ.get('TEDM_PREC'), choices=['bf16x3', 'bf16', 'fp16x2', 'f16f4'],
+                    help="arithmetic mode of the MFMA contractions; default: the product's (f16f4 for inference, bf16x3 for --mode train)")
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -265,7 +266,9 @@ def main() -> None:
     dm = DiffusionModel(cfg)
     load_synth_weights(dm.model, seed=0)
     dm = dm.to(dev).eval()
-    dm.model.precision = args.prec
+    if args.prec is None:
+        args.prec = dm.model.train_precision if args.mode == 'train' else dm.model.precision
+    dm.model.precision = dm.model.train_precision = args.prec
 
     g = torch.Generator().manual_seed(1234 + rank)
     x0 = torch.rand(B, 1, S, S, generator=g).to(dev)

@@ -116,5 +116,7 @@ class DatasetDM(nn.Module):
             return self.classifier(self.extract_features(x, noise=noise).to(x.device))
         from .head import fused_first_layer
         taps = self._taps_per_step(x, noise)
-        h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[self.diffusion_model.model.precision])
+        unet = self.diffusion_model.model                       # the head trains at the UNet's training precision
+        prec = unet.train_precision if (torch.is_grad_enabled() and self.training) else unet.precision
+        h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
         return self.classifier[1:](h1)

@@ -234,7 +234,12 @@ class Unet(nn.Module):
         self.grad_flat: Optional[Tensor] = None     # one flat fp32 buffer holding every parameter gradient
         self._grad_views: Dict[str, Tensor] = {}
         self._grad_handle = None
-        self.precision = os.environ.get('TEDM_PREC', 'bf16x3')   # 'bf16x3' (parity mode) | 'bf16'
+        # Arithmetic mode of the MFMA contractions (tedm_hip.h TEDM_PREC_*).  Inference default 'f16f4' (fp16 MFMA + one
+        # block-scaled fp4 MFMA for the cross terms: eps 2e-4 from the fp32 reference, gate 1e-3); training forwards /
+        # backwards default to 'bf16x3' (gradients within 1e-4 per tensor of fp32 autograd).  TEDM_PREC / TEDM_TRAIN_PREC
+        # override; switching modes repacks the weights once.
+        self.precision = os.environ.get('TEDM_PREC', 'f16f4')
+        self.train_precision = os.environ.get('TEDM_TRAIN_PREC', os.environ.get('TEDM_PREC', 'bf16x3'))
         self._module_ws: Optional[Tensor] = None
         for name, mod in self.named_modules():                  # back-reference for stand-alone calls (not a registered sub-module)
             if isinstance(mod, (ResnetBlock, Residual)):
@@ -285,14 +290,19 @@ class Unet(nn.Module):
         sd['time_mlp.0.freqs'] = self.time_mlp[0].freqs
         return sd
 
-    def _sync_params(self, device: torch.device, stream_ptr: int):
+    def _prec_name(self, training: bool) -> str:
+        name = self.train_precision if training else self.precision
+        if name not in _lib.PREC_BY_NAME:
+            raise ValueError(f'unknown precision {name!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
+        return name
+
+    def _sync_params(self, device: torch.device, stream_ptr: int, training: bool = False):
         """(Re)bind parameter pointers and repack when anything changed (load_state_dict,
-        optimizer step, .to())."""
+        optimizer step, .to(), arithmetic mode)."""
         L = _lib.lib()
         tensors = self._native_tensors()
-        if self.precision not in _lib.PREC_BY_NAME:
-            raise ValueError(f'unknown precision {self.precision!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
-        fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values()) + (self.precision,)
+        prec = self._prec_name(training)
+        fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values()) + (prec,)
         if fp == self._fingerprint:
             return
         self._bound = []
@@ -309,14 +319,12 @@ class Unet(nn.Module):
                 tt = tt.float().contiguous()
             self._bound.append(tt)
             _lib.check(L.tedm_unet_set_param(self._handle, k.encode(), tt.data_ptr(), tt.numel()), f'set_param({k})')
-        _lib.check(L.tedm_unet_set_precision(self._handle, _lib.PREC_BY_NAME[self.precision]), 'set_precision')
+        _lib.check(L.tedm_unet_set_precision(self._handle, _lib.PREC_BY_NAME[prec]), 'set_precision')
         _lib.check(L.tedm_unet_pack(self._handle, stream_ptr), 'tedm_unet_pack')
         self._fingerprint = fp
 
-    def _flags(self, taps_only: bool, trace: bool) -> int:
-        if self.precision not in _lib.PREC_BY_NAME:
-            raise ValueError(f'unknown precision {self.precision!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
-        f = _lib.PREC_BY_NAME[self.precision] << _lib.FWD_PREC_SHIFT
+    def _flags(self, taps_only: bool, trace: bool, training: bool = False) -> int:
+        f = _lib.PREC_BY_NAME[self._prec_name(training)] << _lib.FWD_PREC_SHIFT
         if taps_only:
             f |= _lib.FWD_TAPS_ONLY
         if trace:
@@ -449,7 +457,7 @@ class Unet(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             self._ensure_handle(dev)
-            self._sync_params(dev, stream)
+            self._sync_params(dev, stream, training=True)
             if self._bwd_fingerprint != self._fingerprint:
                 _lib.check(L.tedm_unet_pack_backward(self._handle, stream), 'tedm_unet_pack_backward')
                 self._bwd_fingerprint = self._fingerprint
@@ -469,7 +477,7 @@ class Unet(nn.Module):
             eps = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=dev)
             _lib.check(L.tedm_unet_forward_train(
                 self._handle, self._train_x.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
-                eps.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(), stream, self._flags(False, False)),
+                eps.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(), stream, self._flags(False, False, training=True)),
                 'tedm_unet_forward_train')
         return eps
 

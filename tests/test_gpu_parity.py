@@ -1,6 +1,7 @@
 """GPU (MI355X): parity of the HIP path -- called through the C ABI -- against the oracle and the
-committed golden vectors.  Tolerances: north_star's 1e-3 rel-L2 on eps for the default (bf16x3)
-mode; individual kernels are held to much tighter bounds so that a layout bug cannot hide."""
+committed golden vectors.  Tolerances: north_star's 1e-3 rel-L2 on eps; the whole-UNet tests run in both the default
+inference mode (f16f4: fp16 MFMA + block-scaled fp4 cross terms, eps ~2e-4) and the high-precision mode (bf16x3, eps ~2e-5);
+individual kernels are held to much tighter bounds so that a layout bug cannot hide."""
 import ctypes as C
 import json
 from argparse import Namespace
@@ -14,7 +15,16 @@ pytestmark = pytest.mark.gpu
 
 EPS_GATE = 1e-3          # BASELINE.json north_star: eps within 1e-3 rel (fp32 CPU reference)
 KERNEL_TOL = 5e-5        # single conv, bf16x3 (operand error ~2^-17)
-MODULE_TOL = 2e-4        # per-module trace
+MODULE_TOL = 2e-4        # per-module trace, bf16x3
+MODE_TOL = {'bf16x3': dict(module=MODULE_TOL, eps=EPS_GATE / 10), 'f16f4': dict(module=1e-3, eps=EPS_GATE / 2)}
+
+
+def mtol(m):
+    return MODE_TOL[m.precision]['module']
+
+
+def etol(m):
+    return MODE_TOL[m.precision]['eps']
 
 
 def rel(a, b):
@@ -254,9 +264,11 @@ def test_linattn_fused_sweeps(lib, dev, B, hw, Cc):
 
 
 # ------------------------------------------------------------------------------------------------
-def make_unet(dim, seed, dev):
+def make_unet(dim, seed, dev, prec=None):
     from tedm_amd import Unet, load_synth_weights
     m = Unet(dim)
+    if prec is not None:
+        m.precision = prec
     load_synth_weights(m, seed=seed)
     return m.to(dev).eval()
 
@@ -265,9 +277,9 @@ def oracle_weights(m):
     return {k: v.detach().cpu() for k, v in m.state_dict().items()}
 
 
-@pytest.fixture(scope='module')
-def unet64(dev):
-    return make_unet(64, 0, dev)
+@pytest.fixture(scope='module', params=['f16f4', 'bf16x3'])
+def unet64(dev, request):
+    return make_unet(64, 0, dev, request.param)
 
 
 def test_q_sample(dev):
@@ -285,10 +297,11 @@ def test_q_sample(dev):
     assert float((xt2.cpu() - O.q_sample(bufs, x0 * 2 - 1, t, noise)).abs().max()) < 1e-6
 
 
-def test_module_trace_mini_vs_golden(dev, golden_dir):
+@pytest.mark.parametrize('prec', ['f16f4', 'bf16x3'])
+def test_module_trace_mini_vs_golden(dev, golden_dir, prec):
     """dim-32 model, 16x16 (every tile ragged): each module output against the reference's own."""
     g = np.load(golden_dir / 'trace_d32_s16.npz')
-    m = make_unet(32, 3, dev)
+    m = make_unet(32, 3, dev, prec)
     with torch.no_grad():
         eps, _ = m.native_forward(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev), trace=True)
     names = [k[2:] for k in g.files if k.startswith('m:')]
@@ -296,10 +309,10 @@ def test_module_trace_mini_vs_golden(dev, golden_dir):
     for nm in names:
         assert nm in m.last_trace, f'{nm} missing from native trace {sorted(m.last_trace)}'
         e = rel(m.last_trace[nm], g['m:' + nm])
-        if not e < MODULE_TOL:
+        if not e < mtol(m):
             bad.append((nm, e))
     assert not bad, bad
-    assert rel(eps, g['eps']) < MODULE_TOL
+    assert rel(eps, g['eps']) < mtol(m)
 
 
 def test_eps_and_taps_vs_golden_64(dev, golden_dir, unet64):
@@ -307,8 +320,8 @@ def test_eps_and_taps_vs_golden_64(dev, golden_dir, unet64):
     with torch.no_grad():
         eps, taps = unet64.native_forward(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev), want_taps=True)
     e = rel(eps, g['eps'])
-    print(f'eps rel-L2 vs reference golden (64x64, bf16x3): {e:.3e}')
-    assert e < EPS_GATE
+    print(f'eps rel-L2 vs reference golden (64x64, {unet64.precision}): {e:.3e}')
+    assert e < etol(unet64)
     for i, tp in enumerate(taps):
         assert tuple(tp.shape) == (2, (512, 256, 128, 64)[i], 8 * 2 ** i, 8 * 2 ** i)
         assert rel(tp[:, ::4, ::2, ::2], g[f'tap{i}_sub']) < EPS_GATE
@@ -327,8 +340,8 @@ def test_eps_vs_golden_256(dev, golden_dir, unet64):
     with torch.no_grad():
         eps = unet64(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev))
     e = rel(eps, g['eps'])
-    print(f'eps rel-L2 vs reference golden (256x256, bf16x3): {e:.3e}')
-    assert e < EPS_GATE
+    print(f'eps rel-L2 vs reference golden (256x256, {unet64.precision}): {e:.3e}')
+    assert e < etol(unet64)
 
 
 def test_precision_modes(dev, golden_dir, unet64):
@@ -338,13 +351,14 @@ def test_precision_modes(dev, golden_dir, unet64):
     g = np.load(golden_dir / 'eps_d64_s64.npz')
     x, t = torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev)
     errs = {}
+    keep = unet64.precision
     try:
         for mode in ('bf16', 'fp16x2', 'f16f4', 'bf16x3'):
             unet64.precision = mode
             with torch.no_grad():
                 errs[mode] = rel(unet64(x, t), g['eps'])
     finally:
-        unet64.precision = 'bf16x3'
+        unet64.precision = keep
     print('eps rel-L2 by precision mode: ' + '  '.join(f'{k} {v:.3e}' for k, v in errs.items()))
     assert errs['bf16x3'] < EPS_GATE / 10
     assert errs['bf16x3'] < errs['fp16x2'] < errs['bf16'] < 0.1
@@ -361,9 +375,9 @@ def test_vs_oracle_ragged_shape(dev, unet64):
     eps_o, trace_o = O.unet_forward(oracle_weights(unet64), x, t, return_trace=True)
     with torch.no_grad():
         eps, _ = unet64.native_forward(x.to(dev), t.to(dev), trace=True)
-    bad = [(k, rel(v, trace_o[k])) for k, v in unet64.last_trace.items() if not rel(v, trace_o[k]) < MODULE_TOL]
+    bad = [(k, rel(v, trace_o[k])) for k, v in unet64.last_trace.items() if not rel(v, trace_o[k]) < mtol(unet64)]
     assert not bad, bad
-    assert rel(eps, eps_o) < EPS_GATE
+    assert rel(eps, eps_o) < etol(unet64)
 
 
 def test_forward_hooks_fire(dev, golden_dir, unet64):
@@ -509,21 +523,21 @@ def test_standalone_submodule_calls_like_global_cl(dev):
         ref = torch.nn.functional.conv2d(x, p['init_conv.weight'], p['init_conv.bias'], padding=3)
         for i, (b1, b2, attn, down) in enumerate(m.downs):
             y = b1(y, None); ref = O.resnet_block(p, f'downs.{i}.0', ref, None, 8)
-            assert rel(y, ref) < MODULE_TOL, f'downs.{i}.0'
+            assert rel(y, ref) < mtol(m), f'downs.{i}.0'
             y = b2(y, None); ref = O.resnet_block(p, f'downs.{i}.1', ref, None, 8)
             y = attn(y); ref = O.linear_attention(p, f'downs.{i}.2', ref)
-            assert rel(y, ref) < MODULE_TOL, f'downs.{i}.2'
+            assert rel(y, ref) < mtol(m), f'downs.{i}.2'
             y = down(y.contiguous())
             ref = torch.nn.functional.conv2d(ref, p[f'downs.{i}.3.weight'], p[f'downs.{i}.3.bias'], stride=2 if i < 3 else 1, padding=1)
         y = m.mid_block1(y, None); ref = O.resnet_block(p, 'mid_block1', ref, None, 8)
         y = m.mid_attn(y); ref = O.full_attention(p, 'mid_attn', ref)
         y = m.mid_block2(y, None); ref = O.resnet_block(p, 'mid_block2', ref, None, 8)
-        assert rel(y, ref) < 5 * MODULE_TOL
+        assert rel(y, ref) < 5 * mtol(m)
         # a decoder block on an explicit torch.cat input, with a time embedding (FiLM)
         temb = torch.randn(2, 128, generator=g)
         xin = torch.randn(2, 128 + 64, 8, 8, generator=g)
         out = m.ups[1][0](xin.to(dev), temb.to(dev))
-        assert rel(out, O.resnet_block(p, 'ups.1.0', xin, temb, 8)) < MODULE_TOL
+        assert rel(out, O.resnet_block(p, 'ups.1.0', xin, temb, 8)) < mtol(m)
     with pytest.raises(NotImplementedError):
         m.ups[1][0](xin.to(dev).requires_grad_(True), temb.to(dev))
 
@@ -538,7 +552,7 @@ def test_edge_shapes_vs_oracle(dev, shape):
     x, t = torch.randn(*shape, generator=g), torch.randint(0, 1000, (shape[0],), generator=g)
     with torch.no_grad():
         eps = m(x.to(dev), t.to(dev))
-    assert rel(eps, O.unet_forward(oracle_weights(m), x, t, dim=32)) < 1e-4
+    assert rel(eps, O.unet_forward(oracle_weights(m), x, t, dim=32)) < etol(m)
 
 
 def test_largest_image_512_is_finite(dev, unet64):
