@@ -79,6 +79,9 @@ int tedm_set_tuning(const char* key, int value);
  * flops and bytes. */
 int tedm_profile_enable(int level);
 int tedm_profile_reset(void);
+/* level 1 only: bracket just the launches whose label equals `label` (NULL / "" = every convolution).  An event pair costs
+ * ~5 us of launch gap, so a timed region that wants one kernel's duration should not pay for the other 74 convolutions. */
+int tedm_profile_filter(const char* label);
 int tedm_profile_collect(void);
 int tedm_profile_count(void);
 int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, double* ms, double* flops, double* bytes);

@@ -81,6 +81,7 @@ _SIGNATURES = {
     'tedm_op_linattn_fused': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_longlong, _P, _P, _P, C.c_int, _P]),
     'tedm_profile_enable': (C.c_int, [C.c_int]),
     'tedm_profile_reset': (C.c_int, []),
+    'tedm_profile_filter': (C.c_int, [C.c_char_p]),
     'tedm_profile_collect': (C.c_int, []),
     'tedm_profile_count': (C.c_int, []),
     'tedm_profile_entry': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double),

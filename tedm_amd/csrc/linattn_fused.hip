@@ -44,17 +44,21 @@ struct LaArgs {
 TEDM_DEVFN int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
 constexpr int KS = 2, KC = 16 * KS;             // channels per staged chunk
-constexpr int PSTRIDE = KS * 32 + 16;           // LDS bytes per pixel per plane (odd multiple of 16)
+// LDS bytes per pixel per plane (odd multiples of 16): bf16 / fp16 planes 80; F16F4 one 112-byte record
+// [fp16 x32 | fp4 residual x32 | fp4 copy x32 | 2 scale bytes | pad] exactly as conv_igemm.inc stages it
+constexpr int pstride(int prec) { return prec == TEDM_PREC_F16F4 ? 112 : KS * 32 + 16; }
 
 template <int EPI> struct LaTile { static constexpr int MT = EPI == LA_CTX ? 2 : 4; };   // M-tiles (32 px) per tile
 
 template <int EPI, int PREC>
 __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     constexpr int MT = LaTile<EPI>::MT, TP = MT * 32, NIT = MT / 2;   // TP*4 pieces / 256 threads
+    constexpr bool F4 = PREC == TEDM_PREC_F16F4;
+    constexpr int PSTRIDE = pstride(PREC);
     constexpr int REGION = TP * PSTRIDE;
     constexpr int NT = EPI == LA_CTX ? 2 : 1;                    // weight tiles per wave (k [, v])
     constexpr int NPL = PREC == TEDM_PREC_BF16X3 ? 2 : 1;        // activation planes in LDS
-    constexpr int NPB = PREC == TEDM_PREC_BF16 ? 1 : 2;          // weight planes
+    constexpr int NPB = F4 ? 3 : (PREC == TEDM_PREC_BF16 ? 1 : 2);   // weight fragments per (tile, chunk) [F4] / planes per 16-channel step
     constexpr int BUFSZ = REGION * NPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -125,7 +129,19 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 }
             }
             const int lofs = ((tid >> 2) + k * 64) * PSTRIDE + piece * 16;
-            if (PREC == TEDM_PREC_FP16X2) {
+            if (F4) {
+                float lo[8], m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+                unsigned e_v4, e_lo;
+                f4_scales(quad_max(m), e_v4, e_lo);
+                const uint4 hi = split8_f16_res(v, lo);
+                char* rec = base + ((tid >> 2) + k * 64) * PSTRIDE;
+                *(uint4*)(rec + piece * 16) = hi;
+                *(unsigned*)(rec + 64 + piece * 4) = cvt8_fp4(lo, e_lo);
+                *(unsigned*)(rec + 80 + piece * 4) = cvt8_fp4(v, e_v4);
+                if (piece == 0) *(unsigned short*)(rec + 96) = (unsigned short)(e_lo | (e_v4 << 8));
+            } else if (PREC == TEDM_PREC_FP16X2) {
                 *(uint4*)(base + lofs) = cvt8_f16(v);
             } else {
                 uint4 hi, lo;
@@ -151,6 +167,17 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
         }
         // weights of this chunk (L2 hits): in flight across the staging + barrier below
         uint4 bq[KS][NT][NPB];
+        unsigned bsc[NT];
+        if (F4) {
+            // conv_pack_f16f4_kernel layout of a 1x1 weight: per (cout tile, 32-channel chunk) 3 fragments, then the scale dwords
+            const unsigned* wsc = (const unsigned*)(wq + (size_t)(3 * hd) * NC * 3 * 64);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bq[0][j][p] = wq[(((size_t)(ct0 + j * hd) * NC + c) * 3 + p) * 64 + lane];
+                bsc[j] = wsc[((size_t)(ct0 + j * hd) * NC + c) * 64 + lane];
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -158,10 +185,38 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
 #pragma unroll
                 for (int p = 0; p < NPB; ++p)
                     bq[ks][j][p] = wq[(((size_t)(ct0 + j * hd) * nk16 + (c * KS + ks)) * 2 + p) * 64 + lane];
+        }
         stage(buf);
         __syncthreads();          // buffer `buf` complete; every wave has finished the MFMAs of iteration it-1
         if (it + 1 < niter) prefetch(it + 1);
         const char* sb = smem + buf * BUFSZ;
+        if constexpr (F4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const char* rec = sb + (mt * 32 + r) * PSTRIDE;
+                const f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + h * 16));
+                const f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + 32 + h * 16));
+                const uint4 aq = *(const uint4*)(rec + 64 + h * 16);
+                const int as = *(const unsigned char*)(rec + 96 + h);
+                i32x8 a4 = {};
+                a4[0] = aq.x; a4[1] = aq.y; a4[2] = aq.z; a4[3] = aq.w;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0][j][0]), b1 = __builtin_bit_cast(f16x8, bq[0][j][1]);
+                    i32x8 b4 = {};
+                    b4[0] = bq[0][j][2].x; b4[1] = bq[0][j][2].y; b4[2] = bq[0][j][2].z; b4[3] = bq[0][j][2].w;
+                    if (EPI == LA_QOUT) {     // D[channel][pixel]: weights are the A operand ([w4 | w_lo] x [a_lo ; a4])
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a1, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b4, a4, acc[mt][j], 4, 4, 0, (int)bsc[j], 0, as);
+                    } else {                  // D[pixel][channel]
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, b4, acc[mt][j], 4, 4, 0, as, 0, (int)bsc[j]);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -315,8 +370,9 @@ template <int EPI>
 int launch_la(const LaArgs& a, int prec, hipStream_t st) {
     dim3 grid(a.B * a.S), block(256);
     constexpr int TP = LaTile<EPI>::MT * 32;
-    const size_t lds1 = 2 * (size_t)TP * PSTRIDE, lds2 = 2 * lds1;   // one / two precision planes, double buffered
-    if (prec == TEDM_PREC_BF16) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_BF16>), grid, block, lds1, st, a);
+    const size_t lds1 = 2 * (size_t)TP * pstride(prec), lds2 = 2 * lds1;   // one / two precision planes, double buffered
+    if (prec == TEDM_PREC_F16F4) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_F16F4>), grid, block, lds1, st, a);
+    else if (prec == TEDM_PREC_BF16) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_BF16>), grid, block, lds1, st, a);
     else if (prec == TEDM_PREC_FP16X2) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_FP16X2>), grid, block, lds1, st, a);
     else hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_BF16X3>), grid, block, lds2, st, a);
     return LAUNCH_OK();

@@ -131,6 +131,8 @@ struct Tape {
 struct ProfEntry { std::string name; long long launches = 0; double ms = 0, flops = 0, bytes = 0; };
 struct Profiler {
     int level = 0;
+    std::string filter;      // level 1: bracket only launches of this kernel label (empty: every convolution)
+    bool skip = false;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     struct Rec { int entry; hipEvent_t a, b; };
@@ -143,6 +145,8 @@ struct Profiler {
         return pool[used++];
     }
     void begin(const std::string& name, double flops, double bytes, hipStream_t st) {
+        skip = level == 1 && !filter.empty() && name != filter;
+        if (skip) return;
         auto it = idx.find(name);
         int i;
         if (it == idx.end()) { i = (int)entries.size(); idx[name] = i; entries.push_back({name}); } else i = it->second;
@@ -151,6 +155,7 @@ struct Profiler {
         if (cur_a) (void)hipEventRecord(cur_a, st);
     }
     void end(hipStream_t st) {
+        if (skip) { skip = false; return; }
         if (cur < 0) return;
         hipEvent_t b = get();
         if (cur_a && b) { (void)hipEventRecord(b, st); pending.push_back({cur, cur_a, b}); }
@@ -318,7 +323,7 @@ int build_plan(tedm_unet* u) {
 // Arithmetic mode of one conv launch: the handle's mode, except that a weight kept in bf16 planes under F16F4 (the
 // LinearAttention to_qkv, shared with linattn_fused.hip) runs bf16x3.
 inline int conv_prec(const ConvW& w, int prec) { return (prec == TEDM_PREC_F16F4 && w.enc == ENC_BF16) ? TEDM_PREC_BF16X3 : prec; }
-inline int la_prec(int prec) { return prec == TEDM_PREC_F16F4 ? TEDM_PREC_BF16X3 : prec; }
+inline int la_prec(int prec) { return prec; }    // linattn_fused.hip consumes every weight encoding
 inline bool prec_ok(int prec) { return prec == TEDM_PREC_BF16X3 || prec == TEDM_PREC_BF16 || prec == TEDM_PREC_FP16X2 || prec == TEDM_PREC_F16F4; }
 
 #define OP(NAME, FLOPS, BYTES, CALL)                                              \
@@ -647,7 +652,7 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
     if (!h->film_b && hipMalloc((void**)&h->film_b, (size_t)h->film_J * 4) != hipSuccess)
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
     for (ConvW* c : h->convs) {
-        c->enc = (h->prec == TEDM_PREC_F16F4 && c->la_qkv) ? ENC_BF16 : prec_encoding(h->prec);
+        c->enc = prec_encoding(h->prec);
         CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, c->enc, st));
     }
     for (ResPlan* r : h->resblocks) {
@@ -1005,6 +1010,7 @@ int tedm_tap_to_features(const float* tap, int B, int h, int w, int C, float* fe
 
 int tedm_profile_enable(int level) { g_prof.level = level < 0 ? 0 : level; return TEDM_OK; }
 int tedm_profile_reset(void) { g_prof.reset(); return TEDM_OK; }
+int tedm_profile_filter(const char* label) { g_prof.filter = label ? label : ""; return TEDM_OK; }
 int tedm_profile_collect(void) { g_err[0] = 0; const int rc = g_prof.collect(); return rc == TEDM_OK ? rc : fail(rc, "event timing failed"); }
 int tedm_profile_count(void) { return (int)g_prof.entries.size(); }
 int tedm_profile_entry(int i, char* name, int name_cap, long long* launches, double* ms, double* flops, double* bytes) {

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EPS_GATE = 1e-3          # BASELINE.json north_star: eps within 1e-3 rel (fp32 CPU reference)
 KERNEL_TOL = 5e-5        # single conv, bf16x3 (operand error ~2^-17)
+F4_TOL = 2e-4            # single conv, f16f4: fp16 main product + fp4 cross terms (operand error ~2^-14)
 MODULE_TOL = 2e-4        # per-module trace, bf16x3
 MODE_TOL = {'bf16x3': dict(module=MODULE_TOL, eps=EPS_GATE / 10), 'f16f4': dict(module=1e-3, eps=EPS_GATE / 2)}
 
@@ -125,9 +126,6 @@ def test_conv_igemm_plain(lib, dev, case):
     assert 1e-4 < rel(outb, ref) < 2e-2
 
 
-F4_TOL = 2e-4           # single conv, f16f4: fp16 main product + fp4 cross terms (operand error ~2^-14)
-
-
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'k{}s{}u{}_{}+{}to{}_{}x{}'.format(*c[:8]))
 def test_conv_igemm_f16f4(lib, dev, case):
     """TEDM_PREC_F16F4: against fp64 (tolerance of the encoding) and against a CPU emulation of the exact encoding
@@ -227,9 +225,10 @@ def test_conv_prologues_and_epilogues(lib, dev):
     assert rel(out, ref) < KERNEL_TOL
 
 
+@pytest.mark.parametrize('prec', [0, 3], ids=['bf16x3', 'f16f4'])
 @pytest.mark.parametrize('B,hw,Cc', [(3, 1000, 64), (32, 2048, 128), (8, 16384, 64)],
                          ids=['ragged', '512-workgroups', 'multi-tile'])
-def test_linattn_fused_sweeps(lib, dev, B, hw, Cc):
+def test_linattn_fused_sweeps(lib, dev, B, hw, Cc, prec):
     """LinearAttention core (unet_model.py:197-207) through the three recompute sweeps, against an fp64
     restatement; also bitwise reproducibility with more workgroups than CUs (regression: lane-divergent
     VMEM blocks once staged stale registers whenever two workgroups shared a CU)."""
@@ -248,7 +247,7 @@ def test_linattn_fused_sweeps(lib, dev, B, hw, Cc):
         ctx = torch.empty(B, 4, 32, 32, device=dev)
         o = torch.empty(B, hw, 128, device=dev)
         _lib.check(lib.tedm_op_linattn_fused(xd.data_ptr(), Cc, gd.data_ptr(), sd.data_ptr(), wd.data_ptr(), B, hw,
-                                             kmax.data_ptr(), ctx.data_ptr(), o.data_ptr(), 0,
+                                             kmax.data_ptr(), ctx.data_ptr(), o.data_ptr(), prec,
                                              torch.cuda.current_stream(dev).cuda_stream), 'tedm_op_linattn_fused')
         outs.append((kmax.cpu(), ctx.cpu(), o.cpu()))
     for a_, b_ in zip(outs[0], outs[1]):
@@ -258,9 +257,10 @@ def test_linattn_fused_sweeps(lib, dev, B, hw, Cc):
     q, k, v = hd(qkv[..., :128]), hd(qkv[..., 128:256]), hd(qkv[..., 256:])
     ctx_ref = torch.einsum('bhdn,bhen->bhde', k.softmax(-1), v / hw)
     o_ref = torch.einsum('bhde,bhdn->bhen', ctx_ref, q.softmax(-2) * 32 ** -0.5).permute(0, 3, 1, 2).reshape(B, hw, 128)
-    assert rel(outs[0][0], k.amax(-1).reshape(B, 128)) < KERNEL_TOL
-    assert rel(outs[0][1], ctx_ref) < KERNEL_TOL
-    assert rel(outs[0][2], o_ref) < KERNEL_TOL
+    tol = KERNEL_TOL if prec == 0 else 4 * F4_TOL         # the softmaxes amplify the projection's 5e-5 (f16f4)
+    e = [rel(outs[0][0], k.amax(-1).reshape(B, 128)), rel(outs[0][1], ctx_ref), rel(outs[0][2], o_ref)]
+    print(f'linattn sweeps prec {prec}: kmax {e[0]:.2e} ctx {e[1]:.2e} o {e[2]:.2e}')
+    assert max(e) < tol
 
 
 # ------------------------------------------------------------------------------------------------
