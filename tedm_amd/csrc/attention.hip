@@ -143,8 +143,25 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------
 // bottleneck attention (models/unet_model.py:229-241): q,k l2-normalised along the TOKEN axis
 // (inv_norm from the to_qkv epilogue), sim = scale * q^T k, softmax over keys, out = attn v.
-// One wave per (sample, head, 32-query tile); two sweeps over the key tiles (row max, then
-// exp / row sum / PV), S^T[key][query] kept in the accumulator so P feeds the PV MFMA directly.
+// One wave per (sample, head, 32-query tile), ONE sweep over the key tiles with a running row max (online softmax:
+// the accumulators are rescaled when it grows).  Both contractions run on v_mfma_f32_32x32x16_f16 with fp16 hi/lo
+// operands (hi*hi + lo*hi + hi*lo: ~2^-21, i.e. fp32-grade) -- 12 issues of 32 cycles per (query tile, key tile) instead
+// of the 48 x 64 cycles of the two-sweep v_mfma_f32_32x32x2_f32 form.  S^T[key][query] stays in the accumulator, so P is
+// the B operand of the PV product as it stands (registers 8s..8s+7 = k-step s; V^T is loaded in that row order).
+TEDM_DEVFN void split_frag8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)v[j];
+        hi[j] = hj;
+        lo[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+TEDM_DEVFN f32x16 mfma3_f16(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ inv,
                                                         int B, int ntok, int heads, float scale, float* __restrict__ o,
                                                         float* __restrict__ ml /*(B,ntok,heads,2) row max / row sum, or null*/) {
@@ -162,65 +179,84 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict_
 
     const int qi = qt * 32 + r;
     const bool qok = qi < ntok;
-    float qv[16], ik[16];
+    // B operand of S^T = K Q^T: lane (query r, half hh), k-step s, element j <-> d = 16 s + 8 hh + j
+    f16x8 qh[2], ql[2];
+    float ik[2][8];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int d0 = 4 * (2 * g + hh);
-        const float4 v = *(const float4*)(base + (size_t)(qok ? qi : 0) * C3 + head * 32 + d0);
-        const float4 n = *(const float4*)(ivq + d0);
-        const float4 nk = *(const float4*)(ivk + d0);
-        qv[4 * g] = v.x * n.x * scale; qv[4 * g + 1] = v.y * n.y * scale;
-        qv[4 * g + 2] = v.z * n.z * scale; qv[4 * g + 3] = v.w * n.w * scale;
-        ik[4 * g] = nk.x; ik[4 * g + 1] = nk.y; ik[4 * g + 2] = nk.z; ik[4 * g + 3] = nk.w;
+    for (int s = 0; s < 2; ++s) {
+        const int d0 = 16 * s + 8 * hh;
+        const float* qp = base + (size_t)(qok ? qi : 0) * C3 + head * 32 + d0;
+        const float4 v0 = *(const float4*)qp, v1 = *(const float4*)(qp + 4);
+        const float4 n0 = *(const float4*)(ivq + d0), n1 = *(const float4*)(ivq + d0 + 4);
+        const float4 k0 = *(const float4*)(ivk + d0), k1 = *(const float4*)(ivk + d0 + 4);
+        const float qv[8] = {v0.x * n0.x * scale, v0.y * n0.y * scale, v0.z * n0.z * scale, v0.w * n0.w * scale,
+                             v1.x * n1.x * scale, v1.y * n1.y * scale, v1.z * n1.z * scale, v1.w * n1.w * scale};
+        split_frag8(qv, qh[s], ql[s]);
+        ik[s][0] = k0.x; ik[s][1] = k0.y; ik[s][2] = k0.z; ik[s][3] = k0.w;
+        ik[s][4] = k1.x; ik[s][5] = k1.y; ik[s][6] = k1.z; ik[s][7] = k1.w;
     }
     const int ktiles = (ntok + 31) / 32;
-
-    auto scores = [&](int jt, f32x16& st) {
-        const int kj = jt * 32 + r;
-        const bool kok = kj < ntok;
-        float kv[16];
-        const float* kp = base + (size_t)(kok ? kj : 0) * C3 + heads * 32 + head * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *(const float4*)(kp + 4 * (2 * g + hh));
-            kv[4 * g] = kok ? v.x * ik[4 * g] : 0.f; kv[4 * g + 1] = kok ? v.y * ik[4 * g + 1] : 0.f;
-            kv[4 * g + 2] = kok ? v.z * ik[4 * g + 2] : 0.f; kv[4 * g + 3] = kok ? v.w * ik[4 * g + 3] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[s], qv[s], st, 0, 0, 0);
-    };
-
-    float m = -INFINITY;
-    for (int jt = 0; jt < ktiles; ++jt) {
-        f32x16 st;
-        scores(jt, st);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (jt * 32 + acc_row(i, hh) < ntok) m = fmaxf(m, st[i]);
-    }
-    m = fmaxf(m, __shfl_xor(m, 32));
 
     f32x16 oacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
-    float l = 0.f;
+    float m = -INFINITY, l = 0.f;
     const float* vbase = base + 2 * heads * 32 + head * 32 + r;
     for (int jt = 0; jt < ktiles; ++jt) {
+        // ---- scores S^T[key][query]: A operand = K tile, lane (key r, half hh) ----
+        const int kj = jt * 32 + r;
+        const bool kok = kj < ntok;
+        const float* kp = base + (size_t)(kok ? kj : 0) * C3 + heads * 32 + head * 32;
         f32x16 st;
-        scores(jt, st);
-        float va[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int j = jt * 32 + acc_row(s, hh);
-            va[s] = j < ntok ? vbase[(size_t)j * C3] : 0.f;
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 v0 = *(const float4*)(kp + 16 * s + 8 * hh), v1 = *(const float4*)(kp + 16 * s + 8 * hh + 4);
+            float kv[8] = {v0.x * ik[s][0], v0.y * ik[s][1], v0.z * ik[s][2], v0.w * ik[s][3],
+                           v1.x * ik[s][4], v1.y * ik[s][5], v1.z * ik[s][6], v1.w * ik[s][7]};
+            if (!kok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kv[j] = 0.f;
+            }
+            f16x8 kh, kl;
+            split_frag8(kv, kh, kl);
+            st = mfma3_f16(kh, kl, qh[s], ql[s], st);
         }
+        // ---- V^T rows in the accumulator's row order (issued before the softmax math hides their latency) ----
+        float va[2][8];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float p = (jt * 32 + acc_row(s, hh) < ntok) ? __expf(st[s] - m) : 0.f;
-            l += p;
-            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], p, oacc, 0, 0, 0);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = jt * 32 + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+                va[s][j] = key < ntok ? vbase[(size_t)key * C3] : 0.f;
+            }
+        // ---- online softmax over the keys (rows of st); the query sits on the lane ----
+        float tm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (jt * 32 + acc_row(i, hh) < ntok) tm = fmaxf(tm, st[i]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        const float m_new = fmaxf(m, tm);
+        const float f = (m_new == m) ? 1.f : __expf(m - m_new);       // m = -inf on the first tile: f = 0 (accumulators are 0)
+        l *= f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[i] *= f;
+        m = m_new;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * s + j;
+                pv[j] = (jt * 32 + acc_row(i, hh) < ntok) ? __expf(st[i] - m) : 0.f;
+                l += pv[j];
+            }
+            f16x8 ph, pl, vh, vl;
+            split_frag8(pv, ph, pl);
+            split_frag8(va[s], vh, vl);
+            oacc = mfma3_f16(vh, vl, ph, pl, oacc);                  // O^T[e][query] += V^T[e][key] P[key][query]
         }
     }
     l += __shfl_xor(l, 32);

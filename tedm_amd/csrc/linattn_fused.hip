@@ -43,6 +43,25 @@ struct LaArgs {
 
 TEDM_DEVFN int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+// Registers 8s..8s+7 of a 32x32 fp32 accumulator tile (or any 8 values in that order) as the k-step-s fragment of a
+// v_mfma_f32_32x32x16_f16 that sums over the tile's ROW index (cdna guide section 3, "an accumulator tile as the next MFMA's
+// operand": element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3); both operands of the product must use that order).
+// fp16 hi + fp16 lo (22 significand bits): hi*hi + lo*hi + hi*lo reproduces the fp32 product to ~2^-21, at 6 MFMA issues
+// of 32 cycles per 32x32x32 block instead of the 16 x 64 cycles of v_mfma_f32_32x32x2_f32.
+TEDM_DEVFN void split_frag(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)v[j];
+        hi[j] = hj;
+        lo[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+TEDM_DEVFN f32x16 mfma_f16x3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+}
+
 constexpr int KS = 2, KC = 16 * KS;             // channels per staged chunk
 // LDS bytes per pixel per plane (odd multiples of 16): bf16 / fp16 planes 80; F16F4 one 112-byte record
 // [fp16 x32 | fp4 residual x32 | fp4 copy x32 | 2 scale bytes | pad] exactly as conv_igemm.inc stages it
@@ -80,11 +99,19 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     float kmx = 0.f;
     const bool online = EPI == LA_CTX && a.kmax == nullptr;       // block-uniform
     if (EPI == LA_CTX) kmx = online ? -INFINITY : a.kmax[(size_t)n * hd * 32 + head * 32 + r];
-    float actx[16];
+    // QOUT: A operand ctx^T[e = r][d] of o^T = ctx^T q' in the row order of the q' accumulator (split_frag), times hw so
+    // that the entries (weighted means of v / hw, ~1e-5 at 256x256) sit in fp16's normal range; the 1/hw is applied to o
+    f16x8 cth[2], ctl[2];
     if (EPI == LA_QOUT) {
         const float* cb = a.ctx + ((size_t)n * hd + head) * 1024;
+        const float fhw = (float)a.hw;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) actx[s] = cb[acc_row(s, h) * 32 + r];
+        for (int s = 0; s < 2; ++s) {
+            float cv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cv[j] = cb[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * 32 + r] * fhw;
+            split_frag(cv, cth[s], ctl[s]);
+        }
     }
 
     const int piece = tid & 3;                                    // 8-channel piece of the 32-channel chunk
@@ -282,17 +309,29 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
                 kmx = m_new;
             }
+            // ctx[d][e] += sum_pixel exp(k[pixel][d] - kmx[d]) v[pixel][e]: both accumulators (lane = channel, registers =
+            // pixels) are operands of a product over their row index as they stand (split_frag)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool ok = p0 + mt * 32 + acc_row(i, h) < a.hw;
-                    const float e = ok ? __expf(acc[mt][0][i] - kmx) : 0.f;
-                    zsum += e;
-                    cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(e, ok ? acc[mt][NT - 1][i] : 0.f, cacc, 0, 0, 0);
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    float ev[8], vv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * s_ + j;
+                        const bool ok = p0 + mt * 32 + acc_row(i, h) < a.hw;
+                        ev[j] = ok ? __expf(acc[mt][0][i] - kmx) : 0.f;
+                        vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
+                        zsum += ev[j];
+                    }
+                    f16x8 eh, el, vh, vl;
+                    split_frag(ev, eh, el);
+                    split_frag(vv, vh, vl);
+                    cacc = mfma_f16x3(eh, el, vh, vl, cacc);
                 }
         } else {
             const float scale = 0.17677669529663688110f;         // 32^-0.5
+            const float inv_hw = 1.f / (float)a.hw;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float m = acc[mt][0][0];
@@ -308,13 +347,21 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(actx[s], q[s] * f, oacc, 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    float qv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qv[j] = q[8 * s + j] * f;
+                    f16x8 qh, ql;
+                    split_frag(qv, qh, ql);
+                    oacc = mfma_f16x3(cth[s], ctl[s], qh, ql, oacc);
+                }
                 const long long p = p0 + mt * 32 + r;
                 if (p < a.hw) {
                     float* op = a.o + ((size_t)n * a.hw + p) * (hd * 32) + head * 32 + 4 * h;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
-                        *(float4*)(op + 8 * gq) = make_float4(oacc[4 * gq], oacc[4 * gq + 1], oacc[4 * gq + 2], oacc[4 * gq + 3]);
+                        *(float4*)(op + 8 * gq) = make_float4(oacc[4 * gq] * inv_hw, oacc[4 * gq + 1] * inv_hw, oacc[4 * gq + 2] * inv_hw,
+                                                              oacc[4 * gq + 3] * inv_hw);   // the ctx fragments carry a factor hw
                 }
             }
         }
@@ -330,6 +377,273 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
         for (int i = 0; i < 16; ++i) cp[acc_row(i, h) * 32 + r] = cacc[i];
         if (h == 0) cp[1024 + r] = zsum;
         if (online && h == 0) cp[1056 + r] = kmx;
+    }
+}
+
+// ---- QOUT fused with the rest of the block (F16F4 only, C <= 256) --------------------------------------------------
+//   out = LN_c( to_out( ctx^T softmax_d(q) 32^-0.5 ) + bias ) * g_out + x          (models/unet_model.py:187-190,205-210,
+//                                                                                     Residual :29-36)
+// The separate path writes o (128 ch), reads it back for the 1x1 to_out conv, writes z, and reads z and x again for the
+// LayerNorm + residual: 10 tensor passes of C channels at C = 64.  Here o never leaves the CU: per 64-pixel tile the four
+// head-waves write their 32 output channels as F16F4 operand records into LDS (one 32-channel block per head: exactly
+// the MX block), the to_out product runs as z^T[cout][pixel] = W o^T with the pixel on the lane, and the channel
+// LayerNorm is lane-local sums plus one exchange between the two waves that share a pixel group.  Reads x twice (the
+// second time from L2), writes out once.
+struct LaTailArgs {
+    const float* x; int C; const float* g; const float* lnstats; const void* wqkv; const float* ctx;
+    const void* wout; const float* bias; const float* g_out; float* out;
+    int B; long long hw; int heads, tpw, S;
+};
+
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
+    constexpr int MT = 2, TP = 64, PS = 112;                  // 64-pixel tiles, F16F4 records
+    constexpr int NTH = NT2 / 2;                              // cout tiles per wave in the tail (two waves share a pixel group)
+    constexpr int STG = TP * PS;                              // one staging buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* orec = smem + 2 * STG;                              // [4 heads][64 px] records of o (pixel stride 112 B: conflict-free reads)
+    float2* lnx = (float2*)(orec + TP * 4 * PS);              // [64 px][2 cout halves] (sum, sumsq)
+
+    const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x / a.S, sidx = blockIdx.x - n * a.S;
+    const long long tiles = (a.hw + TP - 1) / TP;
+    const long long t_beg = (long long)sidx * a.tpw, t_end = (t_beg + a.tpw < tiles) ? t_beg + a.tpw : tiles;
+    const int NC = a.C / 32, hd = a.heads;
+    const uint4* wq = (const uint4*)a.wqkv;
+    const unsigned* wqs = (const unsigned*)(wq + (size_t)(3 * hd) * NC * 3 * 64);
+    const uint4* wo = (const uint4*)a.wout;
+    const unsigned* wos = (const unsigned*)(wo + (size_t)NT2 * 4 * 3 * 64);
+    const int piece = tid & 3;
+
+    f16x8 cth[2], ctl[2];                                      // ctx^T fragments x hw (see la_proj_kernel)
+    {
+        const float* cb = a.ctx + ((size_t)n * hd + head) * 1024;
+        const float fhw = (float)a.hw;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float cv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cv[j] = cb[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * 32 + r] * fhw;
+            split_frag(cv, cth[s], ctl[s]);
+        }
+    }
+    const float inv_hw = 1.f / (float)a.hw, scale = 0.17677669529663688110f;
+
+    // staging of one 32-channel chunk of LN(x) for the q projection (as la_proj_kernel; one pixel piece per thread)
+    float4 rv[2]; float2 rs; float4 rg[2]; bool rok;
+    auto prefetch = [&](long long t, int c) __attribute__((always_inline)) {
+        const int cb = c * 32 + piece * 8;
+        rg[0] = *(const float4*)(a.g + cb); rg[1] = *(const float4*)(a.g + cb + 4);
+        long long p = t * TP + (tid >> 2);
+        rok = p < a.hw;
+        p = rok ? p : a.hw - 1;                                // unconditional loads, clamped address, masked value
+        const size_t gp = (size_t)n * a.hw + p;
+        const float4* src = (const float4*)(a.x + gp * a.C + cb);
+        rv[0] = src[0]; rv[1] = src[1];
+        rs = *(const float2*)(a.lnstats + gp * 2);
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const float lr = rok ? rs.x : 0.f, lm = rok ? rs.y : 0.f;
+        float v[8] = {rg[0].x * (rv[0].x * lr - lm), rg[0].y * (rv[0].y * lr - lm), rg[0].z * (rv[0].z * lr - lm), rg[0].w * (rv[0].w * lr - lm),
+                      rg[1].x * (rv[1].x * lr - lm), rg[1].y * (rv[1].y * lr - lm), rg[1].z * (rv[1].z * lr - lm), rg[1].w * (rv[1].w * lr - lm)};
+        if (!rok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        float lo[8], m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+        unsigned e_v4, e_lo;
+        f4_scales(quad_max(m), e_v4, e_lo);
+        const uint4 hi = split8_f16_res(v, lo);
+        char* rec = smem + buf * STG + (tid >> 2) * PS;
+        *(uint4*)(rec + piece * 16) = hi;
+        *(unsigned*)(rec + 64 + piece * 4) = cvt8_fp4(lo, e_lo);
+        *(unsigned*)(rec + 80 + piece * 4) = cvt8_fp4(v, e_v4);
+        if (piece == 0) *(unsigned short*)(rec + 96) = (unsigned short)(e_lo | (e_v4 << 8));
+    };
+
+    // tail roles: pixel group pm (32 px), cout tiles [ch0, ch0 + NTH)
+    const int pm = head & 1, ch0 = (head >> 1) * NTH;
+    // to_out fragments stay in registers across tiles when a wave owns a single cout tile (C = 64)
+    uint4 wfr[NTH == 1 ? 4 : 1][3]; unsigned wfs[NTH == 1 ? 4 : 1];
+    if (NTH == 1) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wfr[c4][p] = wo[(((size_t)ch0 * 4 + c4) * 3 + p) * 64 + lane];
+            wfs[c4] = wos[((size_t)ch0 * 4 + c4) * 64 + lane];
+        }
+    }
+
+    if (t_beg < t_end) prefetch(t_beg, 0);
+    int it = 0;
+    for (long long t = t_beg; t < t_end; ++t) {
+        const long long p0 = t * TP;
+        // ---- phase A: q^T[d][pixel] for this wave's head ------------------------------------------------
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int c = 0; c < NC; ++c, ++it) {
+            const int buf = it & 1;
+            uint4 bq[3]; unsigned bs;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[p] = wq[(((size_t)head * NC + c) * 3 + p) * 64 + lane];
+            bs = wqs[((size_t)head * NC + c) * 64 + lane];
+            stage(buf);
+            __syncthreads();
+            if (c + 1 < NC) prefetch(t, c + 1); else if (t + 1 < t_end) prefetch(t + 1, 0);
+            const char* sb = smem + buf * STG;
+            const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0]), b1 = __builtin_bit_cast(f16x8, bq[1]);
+            i32x8 b4 = {};
+            b4[0] = bq[2].x; b4[1] = bq[2].y; b4[2] = bq[2].z; b4[3] = bq[2].w;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const char* rec = sb + (mt * 32 + r) * PS;
+                const f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + h * 16));
+                const f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + 32 + h * 16));
+                const uint4 aq = *(const uint4*)(rec + 64 + h * 16);
+                const int as = *(const unsigned char*)(rec + 96 + h);
+                i32x8 a4 = {};
+                a4[0] = aq.x; a4[1] = aq.y; a4[2] = aq.z; a4[3] = aq.w;
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a1, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b4, a4, acc[mt], 4, 4, 0, (int)bs, 0, as);
+            }
+        }
+        // softmax over d (lane-local + one exchange), o^T = ctx^T q', encoded as this head's 32-channel record
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float m = acc[mt][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[mt][i]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float q[16], sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { q[i] = __expf(acc[mt][i] - m); sum += q[i]; }
+            sum += __shfl_xor(sum, 32);
+            const float f = scale / sum;
+            f32x16 oacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float qv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qv[j] = q[8 * s + j] * f;
+                f16x8 qh, ql;
+                split_frag(qv, qh, ql);
+                oacc = mfma_f16x3(cth[s], ctl[s], qh, ql, oacc);
+            }
+            // lane (pixel r, half h) holds o[e], e = 8 g + 4 h + c: four groups of 4 consecutive channels
+            float ov[16], om = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ov[i] = oacc[i] * inv_hw; om = fmaxf(om, fabsf(ov[i])); }
+            om = fmaxf(om, __shfl_xor(om, 32));
+            unsigned e_v4, e_lo;
+            f4_scales(om, e_v4, e_lo);
+            const float s_v4 = __builtin_bit_cast(float, e_v4 << 23), s_lo = __builtin_bit_cast(float, e_lo << 23);
+            char* rec = orec + (head * TP + mt * 32 + r) * PS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int e0 = 8 * g + 4 * h;
+                _Float16 hv[4]; float lo[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    hv[c] = (_Float16)__builtin_amdgcn_fmed3f(ov[4 * g + c], -65504.f, 65504.f);
+                    lo[c] = ov[4 * g + c] - (float)hv[c];
+                }
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                f16x4 hq = {hv[0], hv[1], hv[2], hv[3]};
+                *(f16x4*)(rec + e0 * 2) = hq;
+                unsigned ul = 0, uv = 0;
+                ul = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ul, lo[0], lo[1], s_lo, 0);
+                ul = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ul, lo[2], lo[3], s_lo, 1);
+                uv = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(uv, ov[4 * g], ov[4 * g + 1], s_v4, 0);
+                uv = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(uv, ov[4 * g + 2], ov[4 * g + 3], s_v4, 1);
+                *(unsigned short*)(rec + 64 + e0 / 2) = (unsigned short)ul;
+                *(unsigned short*)(rec + 80 + e0 / 2) = (unsigned short)uv;
+            }
+            if (h == 0) *(unsigned short*)(rec + 96) = (unsigned short)(e_lo | (e_v4 << 8));
+        }
+        __syncthreads();                                       // o records of the tile complete
+
+        // ---- phase B: z^T[cout][pixel] = W_out o^T, bias, channel LayerNorm, gain, residual ----------
+        f32x16 z[NTH];
+#pragma unroll
+        for (int k = 0; k < NTH; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[k][i] = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const char* rec = orec + (c4 * TP + pm * 32 + r) * PS;
+            const f16x8 b0 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + h * 16));
+            const f16x8 b1 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + 32 + h * 16));
+            const uint4 bqq = *(const uint4*)(rec + 64 + h * 16);
+            const int bsx = *(const unsigned char*)(rec + 96 + h);
+            i32x8 b4 = {};
+            b4[0] = bqq.x; b4[1] = bqq.y; b4[2] = bqq.z; b4[3] = bqq.w;
+#pragma unroll
+            for (int k = 0; k < NTH; ++k) {
+                uint4 w0, w1, w2; unsigned ws;
+                if (NTH == 1) { w0 = wfr[c4][0]; w1 = wfr[c4][1]; w2 = wfr[c4][2]; ws = wfs[c4]; }
+                else {
+                    const size_t fb = ((size_t)(ch0 + k) * 4 + c4);
+                    w0 = wo[(fb * 3 + 0) * 64 + lane]; w1 = wo[(fb * 3 + 1) * 64 + lane]; w2 = wo[(fb * 3 + 2) * 64 + lane];
+                    ws = wos[fb * 64 + lane];
+                }
+                i32x8 w4 = {};
+                w4[0] = w2.x; w4[1] = w2.y; w4[2] = w2.z; w4[3] = w2.w;
+                z[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), b0, z[k], 0, 0, 0);
+                z[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), b1, z[k], 0, 0, 0);
+                z[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w4, b4, z[k], 4, 4, 0, (int)ws, 0, bsx);
+            }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTH; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(a.bias + (ch0 + k) * 32 + 8 * g + 4 * h);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = z[k][4 * g + c] + bb[c];
+                    z[k][4 * g + c] = v;
+                    s1 += v; s2 = fmaf(v, v, s2);
+                }
+            }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (h == 0) lnx[(pm * 32 + r) * 2 + (head >> 1)] = make_float2(s1, s2);
+        __syncthreads();
+        {
+            const float2 u0 = lnx[(pm * 32 + r) * 2], u1 = lnx[(pm * 32 + r) * 2 + 1];
+            const float invc = 1.f / (float)a.C;
+            const float mean = (u0.x + u1.x) * invc;
+            const float var = fmaxf((u0.y + u1.y) * invc - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + 1e-5f);
+            const long long p = p0 + pm * 32 + r;
+            if (p < a.hw) {
+                const size_t pb = ((size_t)n * a.hw + p) * a.C;
+#pragma unroll
+                for (int k = 0; k < NTH; ++k)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = (ch0 + k) * 32 + 8 * g + 4 * h;
+                        const float4 gv = *(const float4*)(a.g_out + c0);
+                        const float4 xv = *(const float4*)(a.x + pb + c0);
+                        float4 ov4;
+                        ov4.x = (z[k][4 * g] - mean) * rstd * gv.x + xv.x;
+                        ov4.y = (z[k][4 * g + 1] - mean) * rstd * gv.y + xv.y;
+                        ov4.z = (z[k][4 * g + 2] - mean) * rstd * gv.z + xv.z;
+                        ov4.w = (z[k][4 * g + 3] - mean) * rstd * gv.w + xv.w;
+                        *(float4*)(a.out + pb + c0) = ov4;
+                    }
+            }
+        }
     }
 }
 
@@ -393,6 +707,28 @@ int op_linattn_fused(int sweep, const float* x, int C, const float* g, const flo
     if (sweep == LA_KMAX) return launch_la<LA_KMAX>(a, prec, st);
     if (sweep == LA_CTX) return launch_la<LA_CTX>(a, prec, st);
     return launch_la<LA_QOUT>(a, prec, st);
+}
+
+// The fused q sweep + to_out + LayerNorm + residual (F16F4 weight packs; heads == 4, C in {64, 128, 256}).
+bool la_tail_supported(int C, int heads, int prec) { return prec == TEDM_PREC_F16F4 && heads == 4 && (C == 64 || C == 128 || C == 256); }
+int op_linattn_qout_tail(const float* x, int C, const float* g, const float* lnstats, const void* wqkv, const float* ctx,
+                         const void* wout, const float* bias, const float* g_out, int B, long long hw, int heads, float* out,
+                         hipStream_t st) {
+    if (!la_tail_supported(C, heads, TEDM_PREC_F16F4) || !bias || !g_out) return TEDM_EINVAL;
+    LaTailArgs a{};
+    a.x = x; a.C = C; a.g = g; a.lnstats = lnstats; a.wqkv = wqkv; a.ctx = ctx; a.wout = wout; a.bias = bias; a.g_out = g_out;
+    a.out = out; a.B = B; a.hw = hw; a.heads = heads;
+    const long long tiles = (hw + 63) / 64;
+    long long tpw = tiles / 64;                 // <= 64 workgroups per image, of at most 1024 pixels each (as la_split)
+    if (tpw < 1) tpw = 1;
+    if (tpw > 16) tpw = 16;
+    a.tpw = (int)tpw; a.S = (int)((tiles + tpw - 1) / tpw);
+    const size_t lds = 2 * 64 * 112 + 64 * 4 * 112 + 64 * 2 * sizeof(float2);
+    dim3 grid(B * a.S), block(256);
+    if (C == 64) hipLaunchKernelGGL((la_qout_tail_kernel<2>), grid, block, lds, st, a);
+    else if (C == 128) hipLaunchKernelGGL((la_qout_tail_kernel<4>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((la_qout_tail_kernel<8>), grid, block, lds, st, a);
+    return LAUNCH_OK();
 }
 
 int op_linattn_ctx_merge(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st) {

@@ -174,6 +174,7 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
+int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
 
 }  // namespace
@@ -434,6 +435,17 @@ struct Fwd {
                    op_linattn_fused(1, x, C, gpre, ln, a.qkv.wpk, B, hw, heads, nullptr, kmax, cpart, nullptr, nullptr, la_prec(prec), st));
                 OP("linattn_ctx_finalize", 0.0, 4.0 * B * S2 * heads * 1056, op_linattn_ctx_finalize(cpart, B, heads, S2, hw, ctx, st));
                 A->release(cpart); A->release(kmax);
+            }
+            if (g_la_tail && la_tail_supported(C, heads, prec) && a.out.enc == ENC_F16F4 && a.qkv.enc == ENC_F16F4) {
+                // q sweep + to_out + LayerNorm + residual in one kernel: o and z never reach HBM
+                float* res = out_buf ? out_buf : A->alloc((size_t)P * C);
+                OP("linattn_fused<qout+tail>", pf * u->hidden + 2048.0 * P * heads + 2.0 * P * u->hidden * C, 3.0 * pb,
+                   op_linattn_qout_tail(x, C, gpre, ln, a.qkv.wpk, ctx, a.out.wpk, u->P(a.out.key + ".bias"),
+                                        u->P(a.pre + ".fn.fn.to_out.1.g"), B, hw, heads, res, st));
+                A->release(ctx);
+                *out = res;
+                record(a.pre, res, H, W, C);
+                return TEDM_OK;
             }
             o = A->alloc((size_t)P * u->hidden);
             OP("linattn_fused<qout>", pf * u->hidden + 2048.0 * P * heads, pb + 4.0 * P * u->hidden,
@@ -1028,6 +1040,7 @@ int tedm_set_tuning(const char* key, int value) {
     g_err[0] = 0;
     if (!key) return fail(TEDM_EINVAL, "null key");
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
+    if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);

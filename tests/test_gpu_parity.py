@@ -366,6 +366,28 @@ def test_precision_modes(dev, golden_dir, unet64):
     assert errs['f16f4'] < EPS_GATE / 3               # 2e-4 predicted by tools/precision_study.py
 
 
+def test_linattn_fused_tail_matches_separate_kernels(lib, dev, golden_dir):
+    """f16f4: the q sweep fused with to_out + LayerNorm + residual (one kernel, o and z stay on chip) against the separate
+    q sweep / 1x1 conv / ln_res kernels, on the decoder taps (= the outputs of those blocks) and eps; ragged 96x72 too."""
+    from tedm_amd import _lib
+    m = make_unet(64, 0, dev, 'f16f4')
+    g = torch.Generator().manual_seed(21)
+    for shape in ((2, 1, 64, 64), (1, 1, 96, 72)):
+        x, t = torch.randn(*shape, generator=g).to(dev), torch.randint(0, 1000, (shape[0],), generator=g).to(dev)
+        res = {}
+        try:
+            for mode in (1, 0):
+                _lib.check(lib.tedm_set_tuning(b'la_tail', mode), 'tune')
+                with torch.no_grad():
+                    res[mode] = m.native_forward(x, t, want_taps=True)
+        finally:
+            lib.tedm_set_tuning(b'la_tail', 1)
+        assert rel(res[1][0], res[0][0]) < 2e-4
+        for a_, b_ in zip(res[1][1], res[0][1]):
+            assert rel(a_, b_) < 2e-4
+        assert not torch.equal(res[1][0], res[0][0])          # the two paths really differ (the tuning key took effect)
+
+
 def test_vs_oracle_ragged_shape(dev, unet64):
     """B=3, 96x72 (not a power of two, H != W) against the oracle incl. module trace."""
     from oracle import unet_ref as O
