@@ -57,11 +57,15 @@ TEDM_DEVFN uint4 cvt8_f16(const float (&v)[8]) {
 // against the fp32 reference (tools/precision_study.py), gate 1e-3.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-TEDM_DEVFN float quad_max(float v) {      // max over the aligned group of 4 lanes (DPP quad_perm, no LDS)
-    int x = __builtin_bit_cast(int, v);
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));   // [1,0,3,2]
-    x = __builtin_bit_cast(int, v);
-    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));  // [2,3,0,1]
+// max over the aligned group of 4 lanes of a NON-NEGATIVE value (DPP quad_perm, no LDS).  Compared as unsigned integers:
+// the ordering of non-negative floats, without the canonicalising v_max x,x that fmaxf puts in front of every compare.
+TEDM_DEVFN float quad_max(float v) {
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    unsigned y = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);   // [1,0,3,2]
+    x = x > y ? x : y;
+    y = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false);            // [2,3,0,1]
+    x = x > y ? x : y;
+    return __builtin_bit_cast(float, x);
 }
 // E8M0 scale bytes of a block whose largest magnitude is `amax`: the fp4 copy is scaled by 2^(floor(log2 amax) - 2)
 // (OCP MX rule, e2m1 emax = 2, saturating), the fp4 residual by the fp16 half-ulp bound 2^(E-11) (2^-25 in fp16's
@@ -81,16 +85,21 @@ TEDM_DEVFN unsigned cvt8_fp4(const float (&v)[8], unsigned e8m0) {
     u = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(u, v[6], v[7], sc, 3);
     return u;
 }
-// fp16 hi (finite: clamped to +-65504) and the fp32 residual of 8 values
+// fp16 hi (finite: clamped to +-65504) and the fp32 residual of 8 values.  One packed convert per pair and one
+// mixed-precision FMA per value (v_fma_mix_f32: f16 half * -1 + v); written as single-instruction asm because hipcc
+// otherwise converts every value twice (scalar convert for the residual, packed convert for the store) and back.
 TEDM_DEVFN uint4 split8_f16_res(const float (&v)[8], float (&lo)[8]) {
-    f16x8 h;
+    unsigned w[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 hj = (_Float16)__builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
-        h[j] = hj;
-        lo[j] = v[j] - (float)hj;
+    for (int j = 0; j < 4; ++j) {
+        const float a = __builtin_amdgcn_fmed3f(v[2 * j], -65504.f, 65504.f), b = __builtin_amdgcn_fmed3f(v[2 * j + 1], -65504.f, 65504.f);
+        unsigned hp;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * j]) : "v"(hp), "v"(v[2 * j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * j + 1]) : "v"(hp), "v"(v[2 * j + 1]));
+        w[j] = hp;
     }
-    return __builtin_bit_cast(uint4, h);
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 TEDM_DEVFN float wave_sum(float v) {

@@ -81,12 +81,15 @@ struct Res { const char* label; float ms; };
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 10;
     const int rounds = argc > 2 ? atoi(argv[2]) : 3;
+    const char* only = argc > 3 ? argv[3] : nullptr;            // run just this shape (profiling)
     const Shape shapes[] = {
         {"l0_64_64", 64, 0, 64, 256, 0}, {"l0_64_64_gn", 64, 0, 64, 256, 1}, {"l0_128_64", 64, 64, 64, 256, 0},
-        {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l3_768_512", 512, 256, 512, 32, 0},
+        {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l2_384_256", 256, 128, 256, 64, 0},
+        {"l3_512_512_gn", 512, 0, 512, 32, 1}, {"l3_768_512", 512, 256, 512, 32, 0},
     };
     const int B = 32;
     for (const Shape& sh : shapes) {
+        if (only && strcmp(only, sh.name)) continue;
         const int Cin = sh.C1 + sh.C2;
         const size_t n1 = (size_t)B * sh.S * sh.S * sh.C1, n2 = (size_t)B * sh.S * sh.S * sh.C2, no = (size_t)B * sh.S * sh.S * sh.Cout;
         float *x1, *x2 = nullptr, *out, *w, *bias, *ga, *gb, *stats;
@@ -116,11 +119,10 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
             if (sh.Cout < 128) {
-                if (sh.gn) { RUN(v0, 2, 2, 4, 1, "v0 narrow tpw1"); RUNT(v0, 2, 2, 4, 1, 2, "v0 narrow tpw2"); RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow tpw4"); RUNT(v0, 2, 2, 4, 1, 8, "v0 narrow tpw8"); RUN(v0, 4, 2, 4, 1, "v0 4x2x4 16rows"); RUNT(v0, 4, 2, 4, 1, 4, "v0 4x2x4 tpw4"); }
-                else       { RUN(v0, 2, 2, 4, 0, "v0 narrow tpw1"); RUNT(v0, 2, 2, 4, 0, 2, "v0 narrow tpw2"); RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow tpw4"); RUNT(v0, 2, 2, 4, 0, 8, "v0 narrow tpw8"); RUN(v0, 4, 2, 4, 0, "v0 4x2x4 16rows"); RUNT(v0, 4, 2, 4, 0, 4, "v0 4x2x4 tpw4"); }
+                if (sh.gn) { RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow tpw4"); } else { RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow tpw4"); }
             } else {
-                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 wide8w"); RUNT(v0, 2, 4, 4, 1, 2, "v0 wide8w tpw2"); RUN(v0, 2, 4, 8, 1, "v0 2x4x8 wide16"); RUNT(v0, 2, 4, 8, 1, 2, "v0 2x4x8 tpw2"); RUN(v0, 4, 2, 4, 1, "v0 4x2x4 16r x64"); }
-                else       { RUN(v0, 2, 4, 4, 0, "v0 wide8w"); RUNT(v0, 2, 4, 4, 0, 2, "v0 wide8w tpw2"); RUN(v0, 2, 4, 8, 0, "v0 2x4x8 wide16"); RUNT(v0, 2, 4, 8, 0, 2, "v0 2x4x8 tpw2"); RUN(v0, 4, 2, 4, 0, "v0 4x2x4 16r x64"); }
+                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 2x4x4 wide8w"); RUN(v0, 1, 8, 4, 1, "v0 1x8x4 (256 couts)"); RUN(v0, 1, 4, 4, 1, "v0 1x4x4 wide4"); }
+                else       { RUN(v0, 2, 4, 4, 0, "v0 2x4x4 wide8w"); RUN(v0, 1, 8, 4, 0, "v0 1x8x4 (256 couts)"); RUN(v0, 1, 4, 4, 0, "v0 1x4x4 wide4"); }
             }
             all.push_back(res);
         }
