@@ -25,12 +25,16 @@ struct TileSel { int wm, wn, mt; };
 //   id 2 "wide4"  : 1x4 waves, 4 M-tiles -> 128 px x 128 cout
 // stride-2 convs use half the rows (the halo doubles).
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
+//   id 4 "wide256" : 1x8 waves (512 threads), 4 M-tiles -> 128 px x 256 cout
 int g_tile_wide = 3;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v)); 2x4 waves: two wave rows share
                           // every weight fragment (half the L2 weight traffic per FLOP of the 1x4 tile)
 int g_tile_narrow = 1;
 // g_tile_narrow: tile id used when Cout < 128 (tedm_set_tuning("conv_tile_narrow", v))
 
-inline int select_tile_id(int Cout) { return Cout >= 128 ? g_tile_wide : g_tile_narrow; }
+int g_tile_wide256 = 4;   // tile id used when Cout >= 256 (tedm_set_tuning("conv_tile_wide256", v)): 1x8 waves = 256 couts per
+                          // workgroup: every staged input pixel feeds twice the MFMAs of the 128-cout tiles (+5-9 %, conv_lab)
+
+inline int select_tile_id(int Cout) { return Cout >= 256 ? g_tile_wide256 : (Cout >= 128 ? g_tile_wide : g_tile_narrow); }
 inline TileSel tile_geom(int id, int stride) {
     TileSel t;
     switch (id) {
@@ -38,6 +42,7 @@ inline TileSel tile_geom(int id, int stride) {
         case 1: t = TileSel{2, 2, 4}; break;
         case 2: t = TileSel{1, 4, 4}; break;
         case 3: t = TileSel{2, 4, 4}; break;
+        case 4: t = TileSel{1, 8, 4}; break;
         default: t = TileSel{2, 4, 4}; break;
     }
     if (stride == 2) t.mt = t.mt > 1 ? t.mt / 2 : t.mt;
@@ -48,6 +53,7 @@ inline TileSel tile_geom(int id, int stride) {
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tile_wide256") && v >= 0 && v <= 4) { g_tile_wide256 = v; return TEDM_OK; }
     if (!strcmp(key, "conv_prio") && v >= 0 && v <= 3) { g_conv_prio_mode = v; return TEDM_OK; }
     if (!strcmp(key, "conv_solo") && (v == 0 || v == 1)) { g_conv_solo = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_conv_tpw_max = v; return TEDM_OK; }
