@@ -324,10 +324,21 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                         vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
                         zsum += ev[j];
                     }
-                    f16x8 eh, el, vh, vl;
-                    split_frag(ev, eh, el);
-                    split_frag(vv, vh, vl);
-                    cacc = mfma_f16x3(eh, el, vh, vl, cacc);
+                    // ONE fp16 product: the fp16 roundings of e (in [0,1]) and v are independent across the hw pixels the sum
+                    // runs over, so their relative contribution to ctx shrinks like 2^-12 / sqrt(hw) -- far below the
+                    // projection's own error; the normaliser z is summed in fp32 above
+                    // (F16F4 mode only; the other modes keep the fp32-grade hi/lo product)
+                    if (F4) {
+                        f16x8 eh, vh;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { eh[j] = (_Float16)ev[j]; vh[j] = (_Float16)vv[j]; }
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, vh, cacc, 0, 0, 0);
+                    } else {
+                        f16x8 eh, el, vh, vl;
+                        split_frag(ev, eh, el);
+                        split_frag(vv, vh, vl);
+                        cacc = mfma_f16x3(eh, el, vh, vl, cacc);
+                    }
                 }
         } else {
             const float scale = 0.17677669529663688110f;         // 32^-0.5
@@ -655,9 +666,12 @@ __global__ __launch_bounds__(256) void la_ctx_merge_kernel(const float* __restri
     const int i = (blockIdx.x & 3) * 256 + threadIdx.x, d = i >> 5;
     const size_t stride = (size_t)heads * 1088;
     const float* base = part + ((size_t)b * S * heads + head) * 1088;
+    // both loops are latency-bound (S dependent-free loads): unrolled by 8 so that eight loads are in flight per wait
     float M = -INFINITY;
+#pragma unroll 8
     for (int s = 0; s < S; ++s) M = fmaxf(M, base[s * stride + 1056 + d]);
     float c = 0.f, z = 0.f;
+#pragma unroll 8
     for (int s = 0; s < S; ++s) {
         const float* cp = base + s * stride;
         const float w = __expf(cp[1056 + d] - M);
