@@ -542,12 +542,13 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
             for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float qv[8];
+                // q' (softmax probabilities x 32^-0.5, in [0, 0.18]) as ONE fp16 value: its rounding is independent across
+                // the 32 d of the sum; the context keeps hi + lo (it is one matrix per image and head, not noise)
+                f16x8 qh;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) qv[j] = q[8 * s + j] * f;
-                f16x8 qh, ql;
-                split_frag(qv, qh, ql);
-                oacc = mfma_f16x3(cth[s], ctl[s], qh, ql, oacc);
+                for (int j = 0; j < 8; ++j) qh[j] = (_Float16)(q[8 * s + j] * f);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cth[s], qh, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ctl[s], qh, oacc, 0, 0, 0);
             }
             // lane (pixel r, half h) holds o[e], e = 8 g + 4 h + c: four groups of 4 consecutive channels
             float ov[16], om = 0.f;
@@ -561,15 +562,16 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int e0 = 8 * g + 4 * h;
-                _Float16 hv[4]; float lo[4];
+                float lo[4]; unsigned hw2[2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    hv[c] = (_Float16)__builtin_amdgcn_fmed3f(ov[4 * g + c], -65504.f, 65504.f);
-                    lo[c] = ov[4 * g + c] - (float)hv[c];
+                for (int c = 0; c < 2; ++c) {
+                    const float va = __builtin_amdgcn_fmed3f(ov[4 * g + 2 * c], -65504.f, 65504.f);
+                    const float vb = __builtin_amdgcn_fmed3f(ov[4 * g + 2 * c + 1], -65504.f, 65504.f);
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hw2[c]) : "v"(va), "v"(vb));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * c]) : "v"(hw2[c]), "v"(ov[4 * g + 2 * c]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * c + 1]) : "v"(hw2[c]), "v"(ov[4 * g + 2 * c + 1]));
                 }
-                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-                f16x4 hq = {hv[0], hv[1], hv[2], hv[3]};
-                *(f16x4*)(rec + e0 * 2) = hq;
+                *(uint2*)(rec + e0 * 2) = make_uint2(hw2[0], hw2[1]);
                 unsigned ul = 0, uv = 0;
                 ul = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ul, lo[0], lo[1], s_lo, 0);
                 ul = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ul, lo[2], lo[3], s_lo, 1);

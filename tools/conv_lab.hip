@@ -46,7 +46,7 @@ namespace a7 {
 static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-struct Shape { const char* name; int C1, C2, Cout, S, gn; };
+struct Shape { const char* name; int C1, C2, Cout, S, gn; int k = 3; };
 
 template <typename K>
 static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int grid, int iters) {
@@ -76,6 +76,20 @@ static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int
         res.push_back({LABEL, ms});                                                                                  \
     } while (0)
 
+// 1x1 conv (stride 1, no padding): NBUF = 1 (product) or 2 (pipelined double buffer)
+#define RUN1(NS, WM, WN, MT, NBUF_, LABEL)                                                                           \
+    do {                                                                                                             \
+        using G = NS::Geo<1, 1, 1, WM, MT, 2, NBUF_, 3, WM * WN * 64>;                                               \
+        ConvArgs b = a;                                                                                              \
+        const int TR = WM * MT;                                                                                      \
+        b.tiles_y = (b.Ho + TR - 1) / TR; b.tiles_x = (b.Wo + 31) / 32;                                              \
+        b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = 1; b.xcd_order = 1;                                       \
+        const int grid = b.B * b.tiles_x * b.tiles_y * b.ny;                                                         \
+        const float ms = time_kernel(NS::conv_igemm_kernel<1, 1, 1, 0, 0, WM, WN, MT, 2, NBUF_, 0, 3>, b, WM * WN * 64, \
+                                     (size_t)G::LDS, grid, iters);                                                   \
+        res.push_back({LABEL, ms});                                                                                  \
+    } while (0)
+
 struct Res { const char* label; float ms; };
 
 int main(int argc, char** argv) {
@@ -86,6 +100,8 @@ int main(int argc, char** argv) {
         {"l0_64_64", 64, 0, 64, 256, 0}, {"l0_64_64_gn", 64, 0, 64, 256, 1}, {"l0_128_64", 64, 64, 64, 256, 0},
         {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l2_384_256", 256, 128, 256, 64, 0},
         {"l3_512_512_gn", 512, 0, 512, 32, 1}, {"l3_768_512", 512, 256, 512, 32, 0},
+        {"res_768_512", 512, 256, 512, 32, 0, 1}, {"res_384_256", 256, 128, 256, 64, 0, 1}, {"res_192_128", 128, 64, 128, 128, 0, 1},
+        {"res_128_64", 64, 64, 64, 256, 0, 1},
     };
     const int B = 32;
     for (const Shape& sh : shapes) {
@@ -95,6 +111,7 @@ int main(int argc, char** argv) {
         float *x1, *x2 = nullptr, *out, *w, *bias, *ga, *gb, *stats;
         void* wpk;
         CK(hipMalloc(&x1, n1 * 4)); if (n2) CK(hipMalloc(&x2, n2 * 4)); CK(hipMalloc(&out, no * 4));
+        const int T = sh.k * sh.k;
         CK(hipMalloc(&w, (size_t)sh.Cout * Cin * 9 * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
         CK(hipMalloc(&ga, (size_t)B * Cin * 4)); CK(hipMalloc(&gb, (size_t)B * Cin * 4));
         CK(hipMalloc(&stats, (size_t)B * 4096 * sh.Cout * 2 * 4));
@@ -109,15 +126,21 @@ int main(int argc, char** argv) {
             fill(w, (size_t)sh.Cout * Cin * 9, 1.f / sqrtf(Cin * 9.f)); fill(bias, sh.Cout, 0.1f);
             fill(ga, (size_t)B * Cin, 0.1f); fill(gb, (size_t)B * Cin, 0.1f);
         }
-        if (pack_conv_weights(w, sh.Cout, Cin, 3, 3, wpk, ENC_F16F4, 0) != 0) { printf("pack failed\n"); return 1; }
+        if (pack_conv_weights(w, sh.Cout, Cin, sh.k, sh.k, wpk, ENC_F16F4, 0) != 0) { printf("pack failed\n"); return 1; }
         ConvArgs a{};
         a.x1 = x1; a.C1 = sh.C1; a.x2 = x2; a.C2 = sh.C2; a.B = B; a.H = sh.S; a.W = sh.S; a.Ho = sh.S; a.Wo = sh.S; a.Cout = sh.Cout;
         a.wpk = wpk; a.bias = bias; a.out = out; a.stats = stats; a.stats_mode = STATS_SUMSQ; a.nk16 = Cin / 16; a.prec = 3;
         if (sh.gn) { a.pro_a = ga; a.pro_b = gb; }
-        const double flops = 2.0 * B * sh.S * sh.S * sh.Cout * Cin * 9;
+        const double flops = 2.0 * B * sh.S * sh.S * sh.Cout * Cin * T;
         std::vector<std::vector<Res>> all;
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
+            if (sh.k == 1) {
+                a.stats = nullptr; a.stats_mode = STATS_NONE; a.add = out;     // res_conv: epilogue addend (plain) like the product
+                if (sh.Cout < 128) { RUN1(v0, 2, 2, 4, 1, "1x1 narrow nbuf1"); RUN1(v0, 2, 2, 4, 2, "1x1 narrow nbuf2"); }
+                else if (sh.Cout < 256) { RUN1(v0, 2, 4, 4, 1, "1x1 wide8w nbuf1"); RUN1(v0, 2, 4, 4, 2, "1x1 wide8w nbuf2"); RUN1(v0, 1, 4, 4, 1, "1x1 wide4 nbuf1"); RUN1(v0, 1, 4, 4, 2, "1x1 wide4 nbuf2"); }
+                else { RUN1(v0, 1, 8, 4, 1, "1x1 1x8 nbuf1"); RUN1(v0, 1, 8, 4, 2, "1x1 1x8 nbuf2"); RUN1(v0, 2, 4, 4, 1, "1x1 wide8w nbuf1"); RUN1(v0, 2, 4, 4, 2, "1x1 wide8w nbuf2"); RUN1(v0, 1, 4, 4, 2, "1x1 wide4 nbuf2"); }
+            } else
             if (sh.Cout < 128) {
                 if (sh.gn) { RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow tpw4"); } else { RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow tpw4"); }
             } else {
