@@ -22,23 +22,13 @@
 namespace v0 {
 #include "conv_igemm.inc"
 }
-namespace a1 {
-#define CONV_LAB_ABL 1
+namespace sw {
+#define CONV_LAB_NT 1
 #include "conv_igemm.inc"
 }
-#undef CONV_LAB_ABL
+#undef CONV_LAB_NT
 namespace a2 {
 #define CONV_LAB_ABL 2
-#include "conv_igemm.inc"
-}
-#undef CONV_LAB_ABL
-namespace a4 {
-#define CONV_LAB_ABL 4
-#include "conv_igemm.inc"
-}
-#undef CONV_LAB_ABL
-namespace a7 {
-#define CONV_LAB_ABL 7
 #include "conv_igemm.inc"
 }
 #undef CONV_LAB_ABL
@@ -135,21 +125,20 @@ int main(int argc, char** argv) {
         std::vector<std::vector<Res>> all;
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
-            if (sh.k == 1) {
-                a.stats = nullptr; a.stats_mode = STATS_NONE; a.add = out;     // res_conv: epilogue addend (plain) like the product
-                if (sh.Cout < 128) { RUN1(v0, 2, 2, 4, 1, "1x1 narrow nbuf1"); RUN1(v0, 2, 2, 4, 2, "1x1 narrow nbuf2"); }
-                else if (sh.Cout < 256) { RUN1(v0, 2, 4, 4, 1, "1x1 wide8w nbuf1"); RUN1(v0, 2, 4, 4, 2, "1x1 wide8w nbuf2"); RUN1(v0, 1, 4, 4, 1, "1x1 wide4 nbuf1"); RUN1(v0, 1, 4, 4, 2, "1x1 wide4 nbuf2"); }
-                else { RUN1(v0, 1, 8, 4, 1, "1x1 1x8 nbuf1"); RUN1(v0, 1, 8, 4, 2, "1x1 1x8 nbuf2"); RUN1(v0, 2, 4, 4, 1, "1x1 wide8w nbuf1"); RUN1(v0, 2, 4, 4, 2, "1x1 wide8w nbuf2"); RUN1(v0, 1, 4, 4, 2, "1x1 wide4 nbuf2"); }
-            } else
+            if (sh.k == 1) { break; }
             if (sh.Cout < 128) {
-                if (sh.gn) { RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow tpw4"); } else { RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow tpw4"); }
+                if (sh.gn) { RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow"); RUNT(sw, 2, 2, 4, 1, 4, "nt narrow nontemporal stores"); RUNT(a2, 2, 2, 4, 1, 4, "a2 narrow no stores"); }
+                else       { RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow"); RUNT(sw, 2, 2, 4, 0, 4, "nt narrow nontemporal stores"); RUNT(a2, 2, 2, 4, 0, 4, "a2 narrow no stores"); }
+            } else if (sh.Cout < 256) {
+                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 wide8w"); RUN(sw, 2, 4, 4, 1, "nt wide8w nontemporal"); }
+                else       { RUN(v0, 2, 4, 4, 0, "v0 wide8w"); RUN(sw, 2, 4, 4, 0, "nt wide8w nontemporal"); }
             } else {
-                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 2x4x4 wide8w"); RUN(v0, 1, 8, 4, 1, "v0 1x8x4 (256 couts)"); RUN(v0, 1, 4, 4, 1, "v0 1x4x4 wide4"); }
-                else       { RUN(v0, 2, 4, 4, 0, "v0 2x4x4 wide8w"); RUN(v0, 1, 8, 4, 0, "v0 1x8x4 (256 couts)"); RUN(v0, 1, 4, 4, 0, "v0 1x4x4 wide4"); }
+                if (sh.gn) { RUN(v0, 1, 8, 4, 1, "v0 1x8"); RUN(sw, 1, 8, 4, 1, "nt 1x8 nontemporal"); }
+                else       { RUN(v0, 1, 8, 4, 0, "v0 1x8"); RUN(sw, 1, 8, 4, 0, "nt 1x8 nontemporal"); }
             }
             all.push_back(res);
         }
-        for (size_t i = 0; i < all[0].size(); ++i) {
+        for (size_t i = 0; !all.empty() && i < all[0].size(); ++i) {
             std::vector<float> t;
             for (auto& r : all) t.push_back(r[i].ms);
             std::sort(t.begin(), t.end());

@@ -7,7 +7,7 @@ from argparse import Namespace
 from tedm_amd import DiffusionModel, _lib, load_synth_weights
 L=_lib.lib()
 dev=torch.device('cuda:0')
-dm=DiffusionModel(Namespace(normalize=True, dim=64)); load_synth_weights(dm.model, seed=0); dm=dm.to(dev).eval()
+dm=DiffusionModel(Namespace(normalize=True, dim=64)); load_synth_weights(dm.model, seed=0); dm=dm.to(dev).eval()  # default (f16f4) inference arithmetic
 g=torch.Generator().manual_seed(0)
 x=torch.rand(32,1,256,256,generator=g).to(dev); t=torch.randint(0,1000,(32,),generator=g).to(dev)
 with torch.no_grad():

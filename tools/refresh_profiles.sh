@@ -4,6 +4,7 @@
 set -e
 tag=${1:?usage: refresh_profiles.sh <tag>}
 cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 python bench.py > gpurun_out/${tag}_bench.log 2>&1 && tail -1 gpurun_out/${tag}_bench.log > profiles/${tag}_bench.json
 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_train.json
@@ -20,4 +21,7 @@ python tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_wr
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_train -o train -- python bench.py --mode train --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/rocpd_summary.py gpurun_out/${tag}_train/train_results.db 4 70 > profiles/${tag}_train_kernel_stats.txt
 python tools/conv_shape_profile.py > profiles/${tag}_conv_shape_profile.txt 2>/dev/null
+# per-dispatch timeline of one forward step (every kernel in launch order)
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/trace_one_step.py gpurun_out/${tag}_trace > profiles/${tag}_step_timeline.txt
 echo "profiles/${tag}_* written"
