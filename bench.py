@@ -356,20 +356,37 @@ def main() -> None:
             achieved = flops / (ms * 1e-3) / 1e12
             conv_ms = sum(e[2] for e in conv_all)                  # all convolutions: from the untimed profiled step
             step_ms_prof = 1e3 * elapsed / K
+            # which roofline bounds this kernel: algorithmic flops at the dense MFMA peak vs algorithmic bytes at the HBM peak
+            t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), byts / (PEAK_HBM_GBS * 1e9)
+            hbm_bound = t_hbm > t_mfma
+            gbs = byts / (ms * 1e-3) / 1e9
+            mp = {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec]
             out['roofline'] = {
-                'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(name),
+                'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': name,
+                'achieved': round(gbs if hbm_bound else achieved, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(name),
                 'launches': launches, 'avg_us': round(1e3 * ms / launches, 2),
                 'alg_gflop_per_launch': round(flops / launches / 1e9, 3),
                 'alg_mb_per_launch': round(byts / launches / 1e6, 3),
+                'alg_tflops': round(achieved, 2), 'alg_gbs': round(gbs, 1),
                 'kernel_share_of_step': round(ms / (1e3 * elapsed), 4),
                 'all_conv_share_of_step': round(conv_ms / step_ms_prof, 4),
                 'all_conv_tflops': round(sum(e[3] for e in conv_all) / (conv_ms * 1e-3) / 1e12, 2),
-                # `achieved` counts ALGORITHMIC flops; the parity mode issues 3 bf16 MFMA products per algorithmic product (1 for
-                # --prec bf16, 2 for fp16x2), so the matrix pipes are busy `frac * mfma_products` of the nominal peak
-                'mfma_products': {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec],
-                'frac_of_issued_mfma_peak': round(achieved * {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec] / PEAK_BF16_TFLOPS, 4),
+                # `alg_tflops` counts ALGORITHMIC flops; per algorithmic product the arithmetic mode issues `mfma_products` bf16-rate
+                # MFMAs (f16f4: two fp16 + one fp4 K=64 issue per 32 channels = 1.5 per 16), so the matrix pipes carry
+                # `alg_tflops * mfma_products`; the chip sustains ~1.5 PF/s of fp16 MFMA issue under load (power-limited)
+                'mfma_products': mp,
+                'frac_of_issued_mfma_peak': round(achieved * mp / PEAK_BF16_TFLOPS, 4),
+                # the convolution with the largest share among the MFMA-bound ones (Cout >= 128), same event data
+                'mfma_bound_kernel': None,
             }
+            for nm, ln, m_, fl, by in conv_all:
+                if fl / (PEAK_BF16_TFLOPS * 1e12) >= by / (PEAK_HBM_GBS * 1e9):
+                    out['roofline']['mfma_bound_kernel'] = {'kernel': nm, 'alg_tflops': round(fl / (m_ * 1e-3) / 1e12, 2),
+                                                           'frac': round(fl / (m_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                           'avg_us': round(1e3 * m_ / ln, 2), 'from': 'untimed profiled step'}
+                    break
         per_img = elapsed / (B * K)
         scale = (S / 256.0) ** 2
         out['whole_step'] = {
