@@ -67,7 +67,10 @@ constexpr int KS = 2, KC = 16 * KS;             // channels per staged chunk
 // [fp16 x32 | fp4 residual x32 | fp4 copy x32 | 2 scale bytes | pad] exactly as conv_igemm.inc stages it
 constexpr int pstride(int prec) { return prec == TEDM_PREC_F16F4 ? 112 : KS * 32 + 16; }
 
-template <int EPI> struct LaTile { static constexpr int MT = EPI == LA_CTX ? 2 : 4; };   // M-tiles (32 px) per tile
+#ifndef LA_CTX_MT
+#define LA_CTX_MT 2
+#endif
+template <int EPI> struct LaTile { static constexpr int MT = EPI == LA_CTX ? LA_CTX_MT : 4; };   // M-tiles (32 px) per tile
 
 template <int EPI, int PREC>
 __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
