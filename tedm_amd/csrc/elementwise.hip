@@ -173,6 +173,112 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
 }
 
 
+// The same GEMM on v_mfma_f32_32x32x16_f16 with fp16 hi + lo operands (hi*hi + lo*hi + hi*lo: ~2^-21, fp32-grade): the K axis
+// is ordered (input channel, tap row pair, 8 slots) -- k-step s of channel ci holds tap rows ky = 2s (lane half 0) and 2s+1
+// (half 1), slots j = 0..6 = kx, slot 7 and row 7 zero -- so a lane's 8 operand values are 7 consecutive floats of one halo
+// row at compile-time offsets.  48 MFMA issues of 32 cycles per wave (2 rows x 64 couts) instead of 100 x 64 cycles of the
+// fp32 MFMA: the kernel becomes bound by its 256-byte-per-pixel output stream.
+TEDM_DEVFN void stem_split(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hj = (_Float16)v[j];
+        hi[j] = hj;
+        lo[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+template <int NCB>
+__global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int B, int Cin, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS4 = Cin * 4;                                // k-steps
+    float* sx = (float*)smem;                               // [Cin][HR + 1][HC]  (one extra zero row: tap row 7)
+    uint4* swf = (uint4*)(sx + ((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3));     // [k-step][cout tile][hi|lo][64 lanes] B fragments
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
+    int tile = blockIdx.x;
+    const int n = tile / (tiles_x * tiles_y);
+    tile -= n * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * STEM_TR, ox0 = tx * STEM_TC;
+    for (int i = tid; i < Cin * (STEM_HR + 1) * STEM_HC; i += 256) {
+        const int ci = i / ((STEM_HR + 1) * STEM_HC);
+        const int rem = i - ci * (STEM_HR + 1) * STEM_HC;
+        const int hy = rem / STEM_HC, hx = rem - hy * STEM_HC;
+        const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+        const bool ok = hy < STEM_HR && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];          // unconditional load, clamped address
+        sx[i] = ok ? v : 0.f;
+    }
+    // weight fragments: lane (cout li, half hk) of k-step (ci, s) holds w[co][ci][ky = 2 s + hk][kx = j], j < 7
+    for (int f = tid; f < KS4 * NCB * 64; f += 256) {
+        const int ln = f & 63, c = (f >> 6) % NCB, ks = f / (64 * NCB);
+        const int ci = ks >> 2, s_ = ks & 3, co = c * 32 + (ln & 31), ky = 2 * s_ + (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (j < 7 && ky < 7 && co < Cout) ? w[((size_t)co * Cin + ci) * 49 + ky * 7 + j] : 0.f;
+        f16x8 hi, lo;
+        stem_split(v, hi, lo);
+        swf[((ks * NCB + c) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
+        swf[((ks * NCB + c) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
+    }
+    __syncthreads();
+    f32x16 acc[2][NCB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+    for (int ks = 0; ks < KS4; ++ks) {
+        const int ci = ks >> 2, s_ = ks & 3;
+        f16x8 bh[NCB], bl[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            bh[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 0) * 64 + lane]);
+            bl[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 1) * 64 + lane]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            // halo row of output row (2 wave + m), tap row 2 s + lk; row STEM_HR (index 14) is the zero row (tap row 7 of the last rows)
+            const float* ax = sx + (ci * (STEM_HR + 1) + 2 * wave + m + 2 * s_ + lk) * STEM_HC + li;
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) av[j] = ax[j];
+            av[7] = 0.f;
+            if (2 * s_ + lk >= 7) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) av[j] = 0.f;
+            }
+            f16x8 ah, al;
+            stem_split(av, ah, al);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc[m][c], 0, 0, 0);
+                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc[m][c], 0, 0, 0);
+                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc[m][c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int oy = oy0 + 2 * wave + m;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int co = c * 32 + li;
+            const float bs = bias[co];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int ox = ox0 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk;
+                if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = acc[m][c][s_] + bs;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // time MLP: SinusoidalPosEmb -> Linear -> GELU(erf) -> Linear (models/unet_model.py:76-93,287-292)
 // followed by the SiLU every ResnetBlock.time_mlp applies first (:149-152).  One block per sample.
@@ -571,7 +677,13 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
                  int Cout, hipStream_t st) {
     const int tiles = ((W + STEM_TC - 1) / STEM_TC) * ((H + STEM_TR - 1) / STEM_TR);
     const int K = Cin * 49;
-    if (K <= 128 && (Cout == 32 || Cout == 64)) {                 // matrix-core path
+    if (Cin <= 2 && (Cout == 32 || Cout == 64)) {                 // fp16 hi/lo matrix-core path (the model's stem: Cin = 1)
+        const size_t lds = (size_t)((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 4 * (Cout / 32) * 2 * 1024;
+        if (Cout == 32) hipLaunchKernelGGL(stem_conv_f16_kernel<1>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        else hipLaunchKernelGGL(stem_conv_f16_kernel<2>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        return LAUNCH_OK();
+    }
+    if (K <= 128 && (Cout == 32 || Cout == 64)) {                 // exact-fp32 matrix-core path
         const size_t lds = (size_t)((Cin * STEM_HR * STEM_HC + 3) & ~3) * 4 + (size_t)2 * ((K + 1) / 2) * Cout * 4;
         if (Cout == 32) hipLaunchKernelGGL(stem_conv_mfma_kernel<1>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
         else hipLaunchKernelGGL(stem_conv_mfma_kernel<2>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
