@@ -54,7 +54,7 @@ TEDM_DEVFN uint4 cvt8_f16(const float (&v)[8]) {
 // in a single 32-cycle issue: its K = 64 is the concatenation [Al | A4] x [B4 ; Bl] (lanes 0-31 hold k-slots 0-31, lanes
 // 32-63 k-slots 32-63, one scale byte per lane = per 32-slot block; layout pinned on hardware by tools/mfma_probe.hip).
 // Per 32 channels: 2 f16 MFMAs + 1 fp4 MFMA = 96 matrix-pipe cycles instead of the 192 of bf16x3; eps error 2-2.6e-4
-// against the fp32 reference (tools/precision_study.py), gate 1e-3.
+// against the fp32 reference (tests/precision_study.py), gate 1e-3.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // max over the aligned group of 4 lanes of a NON-NEGATIVE value (DPP quad_perm, no LDS).  Compared as unsigned integers:

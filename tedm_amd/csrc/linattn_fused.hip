@@ -18,6 +18,7 @@
 // softmax over d is lane-local and the result is directly the B operand of ctx^T q.
 #include "common.h"
 #include "ops.h"
+#include <type_traits>
 #include "../../include/tedm_hip.h"
 
 namespace {
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 for (int i = 0; i < 16; ++i)
                     if (p0 + mt * 32 + acc_row(i, h) < a.hw) run_max = fmaxf(run_max, acc[mt][0][i]);
         } else if (EPI == LA_CTX) {
+            const bool full_tile = p0 + TP <= a.hw;
             if (online) {
                 // running max of this lane's k channel over the workgroup's pixels; rescale what has been accumulated
                 float tmax = -INFINITY;
@@ -307,13 +309,17 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
                 const float m_new = fmaxf(kmx, tmax);
                 const float f = (m_new == kmx) ? 1.f : __expf(kmx - m_new);     // kmx = -inf on the first tile -> 0 (accumulators are 0)
-                zsum *= f;
+                if (__any(f != 1.f)) {                          // wave-uniform: after the first tiles the running max rarely moves
+                    zsum *= f;
 #pragma unroll
-                for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
+                    for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
+                }
                 kmx = m_new;
             }
             // ctx[d][e] += sum_pixel exp(k[pixel][d] - kmx[d]) v[pixel][e]: both accumulators (lane = channel, registers =
             // pixels) are operands of a product over their row index as they stand (split_frag)
+            auto accum = [&](auto full) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full)::value;      // whole tile inside the image: no per-pixel masks
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int i = 8 * s_ + j;
-                        const bool ok = p0 + mt * 32 + acc_row(i, h) < a.hw;
+                        const bool ok = FULL || p0 + mt * 32 + acc_row(i, h) < a.hw;
                         ev[j] = ok ? __expf(acc[mt][0][i] - kmx) : 0.f;
                         vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
                         zsum += ev[j];
@@ -343,6 +349,8 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                         cacc = mfma_f16x3(eh, el, vh, vl, cacc);
                     }
                 }
+            };
+            if (full_tile) accum(std::true_type{}); else accum(std::false_type{});
         } else {
             const float scale = 0.17677669529663688110f;         // 32^-0.5
             const float inv_hw = 1.f / (float)a.hw;

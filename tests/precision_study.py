@@ -1,8 +1,8 @@
-"""CPU study (test infrastructure, not product): which MFMA operand formats keep eps under the 1e-3 gate?
+"""CPU study (test infrastructure, not product; lives under tests/ because it imports the oracle): which MFMA operand formats keep eps under the 1e-3 gate?
 
 Monkeypatches F.conv2d inside the oracle so that every convolution's operands are rounded the way a
 candidate MFMA scheme would round them, and prints the eps rel-L2 against the untouched fp32 oracle
-on the golden 64x64 inputs.  Run: python tools/precision_study.py [scheme ...]
+on the golden 64x64 inputs.  Run: python tests/precision_study.py [scheme ...]
 """
 import json
 import sys

@@ -363,7 +363,7 @@ def test_precision_modes(dev, golden_dir, unet64):
     assert errs['bf16x3'] < EPS_GATE / 10
     assert errs['bf16x3'] < errs['fp16x2'] < errs['bf16'] < 0.1
     assert errs['fp16x2'] < 3e-3
-    assert errs['f16f4'] < EPS_GATE / 3               # 2e-4 predicted by tools/precision_study.py
+    assert errs['f16f4'] < EPS_GATE / 3               # 2e-4 predicted by tests/precision_study.py
 
 
 def test_linattn_fused_tail_matches_separate_kernels(lib, dev, golden_dir):
