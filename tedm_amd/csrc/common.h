@@ -147,6 +147,10 @@ struct ConvArgs {
     int prec;                      // TEDM_PREC_*
     int prio_mode;                 // 0 none, 1: waves in even SIMD slots run at s_setprio 1 (filled by the launcher)
     unsigned long long* trace;     // diagnostic builds (-DTEDM_DIAG_TRACE) only: per-wave phase timestamps
+    // ups == 3 (KH = 2, template PAD < 0): the four parity convolutions of a nearest-x2 upsample + 3x3 conv.  (H, W) =
+    // (Ho, Wo) is the low-resolution grid; "tile" index t = 4 * spatial tile + parity (a, b); parity weights are wpk_pstride
+    // bytes apart; output pixel (2y + a, 2x + b) of a (2 Ho, 2 Wo) tensor; top / left zero padding (1 - a, 1 - b).
+    size_t wpk_pstride;
 };
 
 int conv_launch(const ConvArgs& a, int KH, int stride, int ups, int pro, hipStream_t st);
@@ -161,4 +165,7 @@ inline int prec_encoding(int prec) { return prec == 2 /*FP16X2*/ ? ENC_F16 : (pr
 int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int enc, hipStream_t st);
 int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int enc,
                             hipStream_t st);
+// nearest-x2 upsample + 3x3 conv == four 2x2 convs on the low-resolution image, one per output parity (a, b): the taps that
+// read the same source pixel are pre-summed.  w3: (Cout, Cin, 3, 3); w2x2: scratch (4, Cout, Cin, 2, 2) fp32; wpk: 4 packs.
+int pack_conv_weights_up2(const float* w3, int Cout, int Cin, float* w2x2, void* wpk, size_t pack_stride, int enc, hipStream_t st);
 int copy_rows(const float* src, float* dst, long long n, hipStream_t st);

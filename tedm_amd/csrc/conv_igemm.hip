@@ -69,9 +69,10 @@ int conv_set_tuning(const char* key, int v) {
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
     const int id = select_tile_id(a.Cout, KH);
     const TileSel t = tile_geom(id, stride);
-    const int pad = KH == 1 ? 0 : (ups == 2 ? 2 : 1), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
+    const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
              ks, nbuf, pro, a.prec);
+    if (ups == 3) snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-1,0,%d,%d,%d,%d,2,%d,%d>", t.wm, t.wn, t.mt, ks, pro, a.prec);
 }
 
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {
@@ -94,6 +95,11 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     const int tile_id = select_tile_id(a.Cout, KH);
     const TileSel t = tile_geom(tile_id, stride);
     const int TR = t.wm * t.mt;
+    if (ups == 3) {                                               // parity convs: the kernel's grid is the low-resolution one
+        if (KH != 2 || a.Ho != 2 * a.H || a.Wo != 2 * a.W || a.stats_mode != STATS_NONE || a.x2) return TEDM_EINVAL;
+        a.Ho = a.H; a.Wo = a.W;
+        a.wpk_pstride = conv_packed_bytes(a.Cout, Cin, 4);
+    }
     a.tiles_y = (a.Ho + TR - 1) / TR;
     a.tiles_x = (a.Wo + 31) / 32;
     a.nk16 = Cin / 16;

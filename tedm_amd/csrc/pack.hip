@@ -138,6 +138,35 @@ __global__ void conv_pack_dgrad_f16f4_kernel(const float* __restrict__ w, int Co
                     lane, KH, KW, tap, (((size_t)ct * NC + c) * T + tap) * 3, ((size_t)ct * NC + c) * KW + kx, wpk, sc);
 }
 
+// W'[a][b][co][ci][dy][dx] = sum of the 3x3 taps (ky, kx) whose source pixel under nearest-x2 upsampling is (dy, dx) of the
+// parity's 2x2 footprint: rows a = 0: {ky 0} | {ky 1, 2};  a = 1: {ky 0, 1} | {ky 2}  (same for columns).
+__global__ void up2_weights_kernel(const float* __restrict__ w3, float* __restrict__ w2, long long n /* Cout*Cin */) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float w[3][3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k / 3][k % 3] = w3[i * 9 + k];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int gy = (a + ky - 1 + 2) / 2 - 1 + (1 - a);    // source row offset (0 or 1) inside the footprint
+                            const int gx = (b + kx - 1 + 2) / 2 - 1 + (1 - b);
+                            if (gy == dy && gx == dx) s += w[ky][kx];
+                        }
+                    w2[(((size_t)(a * 2 + b) * n + i) * 2 + dy) * 2 + dx] = s;
+                }
+}
+
 __global__ void copy_kernel(const float* __restrict__ s, float* __restrict__ d, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -179,6 +208,17 @@ int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, i
     hipLaunchKernelGGL(conv_pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        w, Cout, Cin, KH, KW, ci0, nci, (uint4*)wpk, total, fp16);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
+}
+
+int pack_conv_weights_up2(const float* w3, int Cout, int Cin, float* w2x2, void* wpk, size_t pack_stride, int enc, hipStream_t st) {
+    const long long n = (long long)Cout * Cin;
+    hipLaunchKernelGGL(up2_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w3, w2x2, n);
+    if (hipGetLastError() != hipSuccess) return TEDM_EHIP;
+    for (int pq = 0; pq < 4; ++pq) {
+        const int rc = pack_conv_weights(w2x2 + (size_t)pq * n * 4, Cout, Cin, 2, 2, (char*)wpk + pq * pack_stride, enc, st);
+        if (rc != TEDM_OK) return rc;
+    }
+    return TEDM_OK;
 }
 
 int copy_rows(const float* src, float* dst, long long n, hipStream_t st) {

@@ -51,6 +51,9 @@ struct ConvW {           // one conv weight in packed MFMA-fragment form (handle
     // [x1 (split channels) | x2] carry one pack per input so that each dX is its own launch.
     int split = 0;
     void* wpk_d[2] = {nullptr, nullptr};
+    // Upsample conv (nearest x2 + 3x3): the four 2x2 parity packs of the low-resolution formulation (pack_conv_weights_up2)
+    bool up2 = false;
+    void* wpk_up = nullptr;
 };
 struct ResPlan { std::string pre; int cin = 0, cout = 0; bool has_res = false; int film_off = 0; ConvW c1, c2, res; };
 struct AttnPlan { std::string pre; int C = 0; bool linear = true; ConvW qkv, out; };
@@ -174,6 +177,7 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
+int g_conv_up_split = 1;   // tedm_set_tuning("conv_up_split", 0|1): Upsample as four 2x2 parity convs on the low-resolution image
 int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
 
@@ -204,6 +208,7 @@ struct tedm_unet {
     ~tedm_unet() {
         for (ConvW* c : convs) {
             if (c->wpk) (void)hipFree(c->wpk);
+            if (c->wpk_up) (void)hipFree(c->wpk_up);
             for (void* p : c->wpk_d) if (p) (void)hipFree(p);
         }
         if (film_w) (void)hipFree(film_w);
@@ -308,6 +313,7 @@ int build_plan(tedm_unet* u) {
         u->add_res(L.b2, pre + ".1", dout + din, dout, dout);
         u->add_attn(L.attn, pre + ".2", dout, true);
         L.tail_kind = last ? 1 : 2;
+        L.tail.up2 = !last;
         u->add_conv(L.tail, last ? pre + ".3" : pre + ".3.1", din, dout, 3, true);
     }
     u->add_res(u->fin, "final_res_block", c.dim * 2, c.dim, c.dim);
@@ -346,21 +352,23 @@ struct Fwd {
         if (dry) return TEDM_OK;
         ConvArgs a{};
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = w.cout;
-        a.wpk = w.wpk; a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
+        int k = w.k;
+        a.wpk = w.wpk;
+        if (ups == 1 && w.wpk_up && g_conv_up_split && !x2) { a.wpk = w.wpk_up; k = 2; ups = 3; } a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
         a.pro_a = pa; a.pro_b = pb; a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b;
         a.stats = stats; a.stats_mode = stats_mode; a.prec = conv_prec(w, prec);
         if (g_prof.level >= 1) {
             char label[160];
-            conv_kernel_label(a, w.k, stride, ups, pro, label, sizeof(label));
+            conv_kernel_label(a, k, stride, ups, pro, label, sizeof(label));
             if (g_prof.level >= 3) {                       // level 3: one entry per layer shape
                 const size_t n = strlen(label);
                 snprintf(label + n, sizeof(label) - n, " %d->%d @%dx%d", C1 + C2, w.cout, Ho, Wo);
             }
             const double cin = C1 + C2;
-            g_prof.begin(label, 2.0 * B * Ho * Wo * w.cout * cin * w.k * w.k,
+            g_prof.begin(label, 2.0 * B * Ho * Wo * w.cout * cin * k * k,       // executed MACs (parity form: 4 taps per output)
                          4.0 * B * ((double)H * W * cin + (double)Ho * Wo * w.cout * (add ? 2 : 1)), st);
         }
-        const int rc = conv_launch(a, w.k, stride, ups, pro, st);
+        const int rc = conv_launch(a, k, stride, ups, pro, st);
         if (g_prof.level >= 1) g_prof.end(st);
         if (rc != TEDM_OK) return fail(rc, "conv launch failed for %s (k=%d cin=%d cout=%d)", w.key.c_str(), w.k, C1 + C2, w.cout);
         return TEDM_OK;
@@ -666,6 +674,12 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
     for (ConvW* c : h->convs) {
         c->enc = prec_encoding(h->prec);
         CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, c->enc, st));
+        if (c->up2) {
+            const size_t ps = conv_packed_bytes(c->cout, c->cin, 4), wb = (size_t)16 * c->cout * c->cin * 4;
+            if (!c->wpk_up && hipMalloc(&c->wpk_up, 4 * ps + wb) != hipSuccess)
+                return fail(TEDM_ENOMEM, "hipMalloc for the parity packs of %s failed", c->key.c_str());
+            CHECK(pack_conv_weights_up2(h->P(c->key + ".weight"), c->cout, c->cin, (float*)((char*)c->wpk_up + 4 * ps), c->wpk_up, ps, c->enc, st));
+        }
     }
     for (ResPlan* r : h->resblocks) {
         CHECK(copy_rows(h->P(r->pre + ".time_mlp.1.weight"), h->film_w + (size_t)r->film_off * h->tdim, (long long)2 * r->cout * h->tdim, st));
@@ -1041,6 +1055,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!key) return fail(TEDM_EINVAL, "null key");
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
+    if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
@@ -1060,9 +1075,15 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     else if ((k == 3 || k == 1) && stride == 1) { Ho = upsample ? 2 * H : H; Wo = upsample ? 2 * W : W; }
     else return fail(TEDM_EINVAL, "unsupported conv geometry k=%d stride=%d", k, stride);
     void* wpk = nullptr;
-    const size_t bytes = conv_packed_bytes(Cout, Cin, k * k);
+    // upsample == 3: the nearest x2 + 3x3 conv of upsample == 1 in its parity form (four 2x2 convs on the low-resolution image)
+    const bool par = upsample == 3;
+    if (par && (k != 3 || x2 || stats)) return fail(TEDM_EINVAL, "parity up-conv: 3x3, one source, no statistics");
+    const size_t ps = conv_packed_bytes(Cout, Cin, 4);
+    const size_t bytes = par ? 4 * ps + (size_t)16 * Cout * Cin * 4 : conv_packed_bytes(Cout, Cin, k * k);
     if (hipMalloc(&wpk, bytes) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
+    int rc = par ? pack_conv_weights_up2(weight_oihw, Cout, Cin, (float*)((char*)wpk + 4 * ps), wpk, ps, prec_encoding(prec), st)
+                 : pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
+    if (par) k = 2;
     if (rc == TEDM_OK) {
         ConvArgs a{};
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -1113,8 +1134,14 @@ int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B
     else if ((k == 3 || k == 1) && stride == 1) { Ho = upsample ? 2 * H : H; Wo = upsample ? 2 * W : W; }
     else return fail(TEDM_EINVAL, "unsupported conv geometry k=%d stride=%d", k, stride);
     void* wpk = nullptr;
-    if (hipMalloc(&wpk, conv_packed_bytes(Cout, Cin, k * k)) != hipSuccess) return fail(TEDM_ENOMEM, "hipMalloc failed");
-    int rc = pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
+    const bool par = upsample == 3;                      // parity form of the up-conv (tedm_op_conv2d)
+    if (par && (k != 3 || x2 || stats)) return fail(TEDM_EINVAL, "parity up-conv: 3x3, one source, no statistics");
+    const size_t ps = conv_packed_bytes(Cout, Cin, 4);
+    if (hipMalloc(&wpk, par ? 4 * ps + (size_t)16 * Cout * Cin * 4 : conv_packed_bytes(Cout, Cin, k * k)) != hipSuccess)
+        return fail(TEDM_ENOMEM, "hipMalloc failed");
+    int rc = par ? pack_conv_weights_up2(weight_oihw, Cout, Cin, (float*)((char*)wpk + 4 * ps), wpk, ps, prec_encoding(prec), st)
+                 : pack_conv_weights(weight_oihw, Cout, Cin, k, k, wpk, prec_encoding(prec), st);
+    if (par) k = 2;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rc == TEDM_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = TEDM_EHIP;
     if (rc == TEDM_OK) {

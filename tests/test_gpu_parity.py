@@ -154,6 +154,57 @@ def test_conv_igemm_f16f4(lib, dev, case):
     assert torch.equal(out1, out)                      # bitwise reproducible
 
 
+UP_CASES = [
+    # Cin, Cout, H, W, B   (low-resolution input; output is 2H x 2W)
+    (64, 32, 12, 20, 2),      # narrow tile, ragged both ways
+    (128, 64, 33, 37, 1),     # odd sizes, several tiles per image
+    (128, 128, 16, 16, 1),    # 2x4-wave tile
+    (256, 128, 9, 40, 2),
+    (512, 256, 8, 8, 2),      # 1x8-wave tile
+]
+
+
+@pytest.mark.parametrize('prec', [3, 0], ids=['f16f4', 'bf16x3'])
+@pytest.mark.parametrize('case', UP_CASES, ids=lambda c: '{}to{}_{}x{}'.format(*c[:4]))
+def test_upconv_parity_form(lib, dev, case, prec):
+    """Upsample (nearest x2 + 3x3, models/unet_model.py:39-44) as four 2x2 parity convolutions on the low-resolution image
+    with pre-summed taps (pack_conv_weights_up2): against fp64 and against the fused-gather form of the same kernel."""
+    Cin, Cout, H, W, B = case
+    x = rnd(B, Cin, H, W, seed=21)
+    w = rnd(Cout, Cin, 3, 3, seed=22, scale=(1.0 / (Cin * 9)) ** 0.5)
+    b = rnd(Cout, seed=23, scale=0.1)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest').double(), w.double(), b.double(), padding=1)
+    out, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=3, prec=prec)
+    assert torch.isfinite(out).all()                   # every output pixel written (the buffer starts as NaN)
+    tol = F4_TOL if prec == 3 else KERNEL_TOL
+    e = rel(out, ref)
+    fused, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=1, prec=prec)
+    print(f'parity up-conv: vs fp64 {e:.2e} (fused gather: {rel(fused, ref):.2e})')
+    assert e < tol
+    assert rel(out, fused) < 2 * tol
+    # residual addend through the strided epilogue
+    add = rnd(B, Cout, 2 * H, 2 * W, seed=24)
+    out2, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=3, add=add, prec=prec)
+    assert rel(out2, ref + add.double()) < tol
+    out3, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=3, prec=prec)
+    assert torch.equal(out3, out)                      # bitwise reproducible
+
+
+def test_upconv_parity_identity(lib, dev):
+    """Exact check of the tap grouping and the output interleave: unit weights on one tap, small-integer data."""
+    B, Cc, H, W = 1, 64, 10, 35
+    x = (torch.arange(B * Cc * H * W, dtype=torch.float32).reshape(B, Cc, H, W) * 7) % 253 - 120.0
+    up = F.interpolate(x, scale_factor=2, mode='nearest')
+    for ky in range(3):
+        for kx in range(3):
+            w = torch.zeros(Cc, Cc, 3, 3)
+            for o in range(Cc):
+                w[o, (o * 5 + 1) % Cc, ky, kx] = 1.0
+            for prec in (3, 0):
+                out, _ = run_conv(lib, dev, x, None, w, None, 3, 1, ups=3, prec=prec)
+                assert torch.equal(out, F.conv2d(up, w, None, padding=1)), (ky, kx, prec)
+
+
 def test_conv_f16f4_scales_and_ranges(lib, dev):
     """Block scales must follow the data: per-pixel magnitudes from 1e-6 to 1e2 (x37 in a few channels; fp16 hi saturates
     at 65504) in one tile, one huge and one tiny weight row."""
