@@ -121,15 +121,22 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     const int piece = tid & 3;                                    // 8-channel piece of the 32-channel chunk
     const int niter = (int)(t_end - t_beg) * NC;                  // flattened (tile, chunk) iterations
 
-    // software pipeline: raw activations of iteration it+1 are in flight while iteration it runs its MFMAs
-    float4 rv[NIT][2]; float2 rs[NIT]; float4 rg[2]; bool rok[NIT];
+    // Software pipeline, prefetch distance 2: the raw activations of iterations it+1 and it+2 are in flight while
+    // iteration it computes (two register sets, loop unrolled by two).  At 64 px x 32 ch x 4 B = 8 KB per iteration and two
+    // workgroups per CU a distance of one keeps 4 MB in flight on the chip, i.e. < 2 TB/s at ~2 us loaded HBM latency:
+    // the sweeps were latency-bound (2.8 us per iteration at 256x256).  VMEM returns in order, so the (L2-hit) weight loads
+    // of iteration it+1 are issued BEFORE prefetch(it+2): queued after it they would wait for its HBM round trip.
+    struct Raw { float4 v[NIT][2]; float2 s[NIT]; bool ok[NIT]; };
+    float* gl = (float*)(smem + 2 * BUFSZ);                      // PreNorm gain [C] (LDS: 16 fewer live registers than per-set copies)
+    for (int i = tid; i < a.C; i += 256) gl[i] = a.g[i];
+    __syncthreads();
     // NB (measured on gfx950 / ROCm 7.2): with these loads inside `if (pixel valid)` blocks, lanes 48-63
     // staged stale registers whenever more than one workgroup shared a CU -- the counted s_waitcnt
     // around lane-divergent VMEM blocks was not sufficient.  Keep every VMEM instruction unconditional.
-    auto prefetch = [&](int it) {
+    auto prefetch = [&](int it, Raw& R) __attribute__((always_inline)) {
+        float4 (&rv)[NIT][2] = R.v; float2 (&rs)[NIT] = R.s; bool (&rok)[NIT] = R.ok;
         const long long t = t_beg + it / NC;
         const int cb = (it % NC) * KC + piece * 8;
-        rg[0] = *(const float4*)(a.g + cb); rg[1] = *(const float4*)(a.g + cb + 4);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             // every lane loads unconditionally (address clamped to the last pixel of the image, value
@@ -143,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
             rs[k] = *(const float2*)(a.lnstats + gp * 2);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int c, const Raw& R) __attribute__((always_inline)) {
+        const float4 (&rv)[NIT][2] = R.v; const float2 (&rs)[NIT] = R.s; const bool (&rok)[NIT] = R.ok;
+        const float4 rg[2] = {*(const float4*)(gl + c * KC + piece * 8), *(const float4*)(gl + c * KC + piece * 8 + 4)};
         char* base = smem + buf * BUFSZ;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -184,21 +193,9 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     };
 
     f32x16 acc[MT][NT];
-    if (niter > 0) prefetch(0);
-    for (int it = 0; it < niter; ++it) {
-        const int c = it % NC, buf = it & 1;
-        const long long p0 = (t_beg + it / NC) * TP;
-        if (c == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
-        }
-        // weights of this chunk (L2 hits): in flight across the staging + barrier below
-        uint4 bq[KS][NT][NPB];
-        unsigned bsc[NT];
+    uint4 bq[KS][NT][NPB];
+    unsigned bsc[NT];
+    auto load_w = [&](int c) __attribute__((always_inline)) {      // weights of chunk c (L2 hits)
         if (F4) {
             // conv_pack_f16f4_kernel layout of a 1x1 weight: per (cout tile, 32-channel chunk) 3 fragments, then the scale dwords
             const unsigned* wsc = (const unsigned*)(wq + (size_t)(3 * hd) * NC * 3 * 64);
@@ -210,16 +207,32 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
             }
         } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int p = 0; p < NPB; ++p)
-                    bq[ks][j][p] = wq[(((size_t)(ct0 + j * hd) * nk16 + (c * KS + ks)) * 2 + p) * 64 + lane];
+                    for (int p = 0; p < NPB; ++p)
+                        bq[ks][j][p] = wq[(((size_t)(ct0 + j * hd) * nk16 + (c * KS + ks)) * 2 + p) * 64 + lane];
         }
-        stage(buf);
+    };
+    // Every VMEM instruction of the loop is issued UNCONDITIONALLY (past the end: a clamped, unused re-load): the waitcnt
+    // pass merges the counts of all paths into a block, and one path without the younger loads turns the counted
+    // vmcnt(N) in front of the staging into vmcnt(0) -- which waits for the prefetch issued one iteration ago as well.
+    Raw R0, R1;
+    if (niter > 0) { prefetch(0, R0); load_w(0); prefetch(niter > 1 ? 1 : 0, R1); }
+    auto body = [&](int it, Raw& R) __attribute__((always_inline)) {
+        const int c = it % NC, buf = it & 1;
+        const long long p0 = (t_beg + it / NC) * TP;
+        if (c == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
+        }
+        stage(buf, c, R);
         __syncthreads();          // buffer `buf` complete; every wave has finished the MFMAs of iteration it-1
-        if (it + 1 < niter) prefetch(it + 1);
         const char* sb = smem + buf * BUFSZ;
         if constexpr (F4) {
 #pragma unroll
@@ -287,7 +300,9 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                     }
                 }
             }
-        if (c != NC - 1) continue;
+        load_w((it + 1) % NC);                                 // this iteration's fragments are dead: next weights, then ...
+        prefetch(it + 2 < niter ? it + 2 : niter - 1, R);      // ... the activations two iterations ahead into the freed set
+        if (c != NC - 1) return;
 
         // ---- epilogue of the tile -------------------------------------------------------------
         if (EPI == LA_KMAX) {
@@ -301,11 +316,21 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
             if (online) {
                 // running max of this lane's k channel over the workgroup's pixels; rescale what has been accumulated
                 float tmax = -INFINITY;
+                if (full_tile) {        // no per-pixel masks; v_max3 on the raw accumulators (fmaxf quiets every input first)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (p0 + mt * 32 + acc_row(i, h) < a.hw) tmax = fmaxf(tmax, acc[mt][0][i]);
+                        for (int i = 0; i < 16; i += 2) {
+                            const float x0 = acc[mt][0][i], x1 = acc[mt][0][i + 1];
+                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(x0), "v"(x1));
+                        }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (p0 + mt * 32 + acc_row(i, h) < a.hw) tmax = fmaxf(tmax, acc[mt][0][i]);
+                }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
                 const float m_new = fmaxf(kmx, tmax);
                 const float f = (m_new == kmx) ? 1.f : __expf(kmx - m_new);     // kmx = -inf on the first tile -> 0 (accumulators are 0)
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
             }
             // ctx[d][e] += sum_pixel exp(k[pixel][d] - kmx[d]) v[pixel][e]: both accumulators (lane = channel, registers =
             // pixels) are operands of a product over their row index as they stand (split_frag)
+            const float kl = kmx * 1.44269504088896340736f;   // exp(k - kmx) = exp2(k log2e - kmx log2e): one FMA + v_exp_f32
             auto accum = [&](auto full) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full)::value;      // whole tile inside the image: no per-pixel masks
 #pragma unroll
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                     for (int j = 0; j < 8; ++j) {
                         const int i = 8 * s_ + j;
                         const bool ok = FULL || p0 + mt * 32 + acc_row(i, h) < a.hw;
-                        ev[j] = ok ? __expf(acc[mt][0][i] - kmx) : 0.f;
+                        ev[j] = ok ? __builtin_amdgcn_exp2f(fmaf(acc[mt][0][i], 1.44269504088896340736f, -kl)) : 0.f;
                         vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
                         zsum += ev[j];
                     }
@@ -387,7 +413,12 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 }
             }
         }
-    }
+    };
+    // pairs only inside the loop (a conditional second half would add a path on which the first half's own prefetch is the
+    // youngest load: the merged count in front of the next staging would drop to vmcnt(0)); an odd tail runs after it
+    int it2 = 0;
+    for (; it2 + 1 < niter; it2 += 2) { body(it2, R0); body(it2 + 1, R1); }
+    if (it2 < niter) body(it2, R0);
 
     if (EPI == LA_KMAX) {
         run_max = fmaxf(run_max, __shfl_xor(run_max, 32));
@@ -417,7 +448,9 @@ struct LaTailArgs {
     int B; long long hw; int heads, tpw, S;
 };
 
-template <int NT2>
+// RAGGED: hw is not a multiple of the 64-pixel tile -- the output stores of the last tile are masked per lane.  The even
+// case keeps every VMEM instruction of the tile loop outside conditional code (exact vmcnt counts, see la_proj_kernel).
+template <int NT2, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
     constexpr int MT = 2, TP = 64, PS = 112;                  // 64-pixel tiles, F16F4 records
     constexpr int NTH = NT2 / 2;                              // cout tiles per wave in the tail (two waves share a pixel group)
@@ -425,13 +458,19 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* orec = smem + 2 * STG;                              // [4 heads][64 px] records of o (pixel stride 112 B: conflict-free reads)
     float2* lnx = (float2*)(orec + TP * 4 * PS);              // [64 px][2 cout halves] (sum, sumsq)
+    float* bgl = (float*)(lnx + TP * 2);                      // to_out bias [C], output LayerNorm gain [C], PreNorm gain [C]
 
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n = blockIdx.x / a.S, sidx = blockIdx.x - n * a.S;
     const long long tiles = (a.hw + TP - 1) / TP;
     const long long t_beg = (long long)sidx * a.tpw, t_end = (t_beg + a.tpw < tiles) ? t_beg + a.tpw : tiles;
-    const int NC = a.C / 32, hd = a.heads;
+    constexpr int NC = NT2;                                   // 32-channel chunks of x == cout tiles of to_out (C / 32)
+    const int hd = a.heads;
+    if (threadIdx.x < a.C) {
+        bgl[threadIdx.x] = a.bias[threadIdx.x]; bgl[a.C + threadIdx.x] = a.g_out[threadIdx.x]; bgl[2 * a.C + threadIdx.x] = a.g[threadIdx.x];
+    }
+    __syncthreads();
     const uint4* wq = (const uint4*)a.wqkv;
     const unsigned* wqs = (const unsigned*)(wq + (size_t)(3 * hd) * NC * 3 * 64);
     const uint4* wo = (const uint4*)a.wout;
@@ -452,11 +491,12 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
     }
     const float inv_hw = 1.f / (float)a.hw, scale = 0.17677669529663688110f;
 
-    // staging of one 32-channel chunk of LN(x) for the q projection (as la_proj_kernel; one pixel piece per thread)
-    float4 rv[2]; float2 rs; float4 rg[2]; bool rok;
-    auto prefetch = [&](long long t, int c) __attribute__((always_inline)) {
+    // staging of one 32-channel chunk of LN(x) for the q projection (as la_proj_kernel; one pixel piece per thread);
+    // prefetch distance 2 with two register sets, weights ahead of the activations in the queue (see la_proj_kernel)
+    struct Raw { float4 v[2]; float2 s; bool ok; };
+    auto prefetch = [&](long long t, int c, Raw& R) __attribute__((always_inline)) {
+        float4 (&rv)[2] = R.v; float2& rs = R.s; bool& rok = R.ok;
         const int cb = c * 32 + piece * 8;
-        rg[0] = *(const float4*)(a.g + cb); rg[1] = *(const float4*)(a.g + cb + 4);
         long long p = t * TP + (tid >> 2);
         rok = p < a.hw;
         p = rok ? p : a.hw - 1;                                // unconditional loads, clamped address, masked value
@@ -465,7 +505,10 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
         rv[0] = src[0]; rv[1] = src[1];
         rs = *(const float2*)(a.lnstats + gp * 2);
     };
-    auto stage = [&](int buf) __attribute__((always_inline)) {
+    auto stage = [&](int buf, int c, const Raw& R) __attribute__((always_inline)) {
+        const float4 (&rv)[2] = R.v; const float2& rs = R.s; const bool rok = R.ok;
+        const float* gl = bgl + 2 * a.C + c * 32 + piece * 8;      // PreNorm gain of this piece's 8 channels
+        const float4 rg[2] = {*(const float4*)gl, *(const float4*)(gl + 4)};
         const float lr = rok ? rs.x : 0.f, lm = rok ? rs.y : 0.f;
         float v[8] = {rg[0].x * (rv[0].x * lr - lm), rg[0].y * (rv[0].y * lr - lm), rg[0].z * (rv[0].z * lr - lm), rg[0].w * (rv[0].w * lr - lm),
                       rg[1].x * (rv[1].x * lr - lm), rg[1].y * (rv[1].y * lr - lm), rg[1].z * (rv[1].z * lr - lm), rg[1].w * (rv[1].w * lr - lm)};
@@ -499,29 +542,42 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
         }
     }
 
-    if (t_beg < t_end) prefetch(t_beg, 0);
-    int it = 0;
+    uint4 bq[3]; unsigned bs;
+    auto load_w = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[p] = wq[(((size_t)head * NC + c) * 3 + p) * 64 + lane];
+        bs = wqs[((size_t)head * NC + c) * 64 + lane];
+    };
+    Raw R0, R1;
+    static_assert(NC % 2 == 0, "two register sets alternate over the chunks of a tile");
+    if (t_beg < t_end) { prefetch(t_beg, 0, R0); load_w(0); prefetch(t_beg, 1, R1); }   // all VMEM unconditional: see la_proj_kernel
+    constexpr bool XPF = NTH == 1;                             // residual input of phase B fetched a whole tile early
     for (long long t = t_beg; t < t_end; ++t) {
         const long long p0 = t * TP;
+        float4 xb[XPF ? NTH : 1][4];
+        if (XPF) {
+            long long p = p0 + pm * 32 + r;
+            p = p < a.hw ? p : a.hw - 1;                       // unconditional loads, clamped address
+            const float* xp = a.x + ((size_t)n * a.hw + p) * a.C;
+#pragma unroll
+            for (int k = 0; k < NTH; ++k)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xb[k][g] = *(const float4*)(xp + (ch0 + k) * 32 + 8 * g + 4 * h);
+        }
         // ---- phase A: q^T[d][pixel] for this wave's head ------------------------------------------------
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-        for (int c = 0; c < NC; ++c, ++it) {
-            const int buf = it & 1;
-            uint4 bq[3]; unsigned bs;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bq[p] = wq[(((size_t)head * NC + c) * 3 + p) * 64 + lane];
-            bs = wqs[((size_t)head * NC + c) * 64 + lane];
-            stage(buf);
+        auto step = [&](int c, int buf, Raw& R) __attribute__((always_inline)) {
+            stage(buf, c, R);
             __syncthreads();
-            if (c + 1 < NC) prefetch(t, c + 1); else if (t + 1 < t_end) prefetch(t + 1, 0);
             const char* sb = smem + buf * STG;
             const f16x8 b0 = __builtin_bit_cast(f16x8, bq[0]), b1 = __builtin_bit_cast(f16x8, bq[1]);
             i32x8 b4 = {};
             b4[0] = bq[2].x; b4[1] = bq[2].y; b4[2] = bq[2].z; b4[3] = bq[2].w;
+            const int bsv = (int)bs;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const char* rec = sb + (mt * 32 + r) * PS;
@@ -533,9 +589,16 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
                 a4[0] = aq.x; a4[1] = aq.y; a4[2] = aq.z; a4[3] = aq.w;
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0, acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a1, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b4, a4, acc[mt], 4, 4, 0, (int)bs, 0, as);
+                acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b4, a4, acc[mt], 4, 4, 0, bsv, 0, as);
             }
-        }
+            // next chunk's weights first, then the activations two chunks ahead into the set just consumed
+            load_w(c + 1 < NC ? c + 1 : 0);
+            const bool wrap = c + 2 >= NC;
+            const long long tn = wrap ? (t + 1 < t_end ? t + 1 : t) : t;       // past the last tile: an unused re-load of it
+            prefetch(tn, wrap ? c + 2 - NC : c + 2, R);
+        };
+#pragma unroll 1
+        for (int c = 0; c < NC; c += 2) { step(c, 0, R0); step(c + 1, 1, R1); }
         // softmax over d (lane-local + one exchange), o^T = ctx^T q', encoded as this head's 32-channel record
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -631,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
         for (int k = 0; k < NTH; ++k)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 bv = *(const float4*)(a.bias + (ch0 + k) * 32 + 8 * g + 4 * h);
+                const float4 bv = *(const float4*)(bgl + (ch0 + k) * 32 + 8 * g + 4 * h);
                 const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -650,15 +713,16 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
             const float var = fmaxf((u0.y + u1.y) * invc - mean * mean, 0.f);
             const float rstd = rsqrtf(var + 1e-5f);
             const long long p = p0 + pm * 32 + r;
-            if (p < a.hw) {
+            if (!RAGGED || p < a.hw) {
                 const size_t pb = ((size_t)n * a.hw + p) * a.C;
 #pragma unroll
                 for (int k = 0; k < NTH; ++k)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c0 = (ch0 + k) * 32 + 8 * g + 4 * h;
-                        const float4 gv = *(const float4*)(a.g_out + c0);
-                        const float4 xv = *(const float4*)(a.x + pb + c0);
+                        const float4 gv = *(const float4*)(bgl + a.C + c0);
+                        float4 xv;
+                        if (XPF) xv = xb[k][g]; else xv = *(const float4*)(a.x + pb + c0);
                         float4 ov4;
                         ov4.x = (z[k][4 * g] - mean) * rstd * gv.x + xv.x;
                         ov4.y = (z[k][4 * g + 1] - mean) * rstd * gv.y + xv.y;
@@ -711,7 +775,8 @@ template <int EPI>
 int launch_la(const LaArgs& a, int prec, hipStream_t st) {
     dim3 grid(a.B * a.S), block(256);
     constexpr int TP = LaTile<EPI>::MT * 32;
-    const size_t lds1 = 2 * (size_t)TP * pstride(prec), lds2 = 2 * lds1;   // one / two precision planes, double buffered
+    const size_t gl = (size_t)a.C * sizeof(float);                        // PreNorm gain
+    const size_t lds1 = 2 * (size_t)TP * pstride(prec) + gl, lds2 = 4 * (size_t)TP * pstride(prec) + gl;   // one / two precision planes, double buffered
     if (prec == TEDM_PREC_F16F4) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_F16F4>), grid, block, lds1, st, a);
     else if (prec == TEDM_PREC_BF16) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_BF16>), grid, block, lds1, st, a);
     else if (prec == TEDM_PREC_FP16X2) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_FP16X2>), grid, block, lds1, st, a);
@@ -750,11 +815,17 @@ int op_linattn_qout_tail(const float* x, int C, const float* g, const float* lns
     if (tpw < 1) tpw = 1;
     if (tpw > 16) tpw = 16;
     a.tpw = (int)tpw; a.S = (int)((tiles + tpw - 1) / tpw);
-    const size_t lds = 2 * 64 * 112 + 64 * 4 * 112 + 64 * 2 * sizeof(float2);
+    const size_t lds = 2 * 64 * 112 + 64 * 4 * 112 + 64 * 2 * sizeof(float2) + 3 * (size_t)C * sizeof(float);
     dim3 grid(B * a.S), block(256);
-    if (C == 64) hipLaunchKernelGGL((la_qout_tail_kernel<2>), grid, block, lds, st, a);
-    else if (C == 128) hipLaunchKernelGGL((la_qout_tail_kernel<4>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((la_qout_tail_kernel<8>), grid, block, lds, st, a);
+    if (hw % 64) {
+        if (C == 64) hipLaunchKernelGGL((la_qout_tail_kernel<2, true>), grid, block, lds, st, a);
+        else if (C == 128) hipLaunchKernelGGL((la_qout_tail_kernel<4, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((la_qout_tail_kernel<8, true>), grid, block, lds, st, a);
+    } else {
+        if (C == 64) hipLaunchKernelGGL((la_qout_tail_kernel<2, false>), grid, block, lds, st, a);
+        else if (C == 128) hipLaunchKernelGGL((la_qout_tail_kernel<4, false>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((la_qout_tail_kernel<8, false>), grid, block, lds, st, a);
+    }
     return LAUNCH_OK();
 }
 

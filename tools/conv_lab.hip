@@ -22,13 +22,23 @@
 namespace v0 {
 #include "conv_igemm.inc"
 }
-namespace sw {
-#define CONV_LAB_NT 1
+namespace a1 {
+#define CONV_LAB_ABL 1
 #include "conv_igemm.inc"
 }
-#undef CONV_LAB_NT
-namespace a2 {
-#define CONV_LAB_ABL 2
+#undef CONV_LAB_ABL
+namespace a4 {
+#define CONV_LAB_ABL 4
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_ABL
+namespace a5 {
+#define CONV_LAB_ABL 5
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_ABL
+namespace a7 {
+#define CONV_LAB_ABL 7
 #include "conv_igemm.inc"
 }
 #undef CONV_LAB_ABL
@@ -126,15 +136,19 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
             if (sh.k == 1) { break; }
+#define ALLV(WM, WN, MT, PRO, TPW, NAME)                                                          \
+    RUNT(v0, WM, WN, MT, PRO, TPW, NAME " product");                                              \
+    RUNT(a1, WM, WN, MT, PRO, TPW, NAME " no staging");                                           \
+    RUNT(a4, WM, WN, MT, PRO, TPW, NAME " no weight reloads");                                    \
+    RUNT(a5, WM, WN, MT, PRO, TPW, NAME " neither");                                              \
+    RUNT(a7, WM, WN, MT, PRO, TPW, NAME " neither, no stores")
             if (sh.Cout < 128) {
-                if (sh.gn) { RUNT(v0, 2, 2, 4, 1, 4, "v0 narrow"); RUNT(sw, 2, 2, 4, 1, 4, "nt narrow nontemporal stores"); RUNT(a2, 2, 2, 4, 1, 4, "a2 narrow no stores"); }
-                else       { RUNT(v0, 2, 2, 4, 0, 4, "v0 narrow"); RUNT(sw, 2, 2, 4, 0, 4, "nt narrow nontemporal stores"); RUNT(a2, 2, 2, 4, 0, 4, "a2 narrow no stores"); }
+                if (sh.gn) { ALLV(2, 2, 4, 1, 4, "narrow"); } else { ALLV(2, 2, 4, 0, 4, "narrow"); }
             } else if (sh.Cout < 256) {
-                if (sh.gn) { RUN(v0, 2, 4, 4, 1, "v0 wide8w"); RUN(sw, 2, 4, 4, 1, "nt wide8w nontemporal"); }
-                else       { RUN(v0, 2, 4, 4, 0, "v0 wide8w"); RUN(sw, 2, 4, 4, 0, "nt wide8w nontemporal"); }
+                if (sh.gn) { ALLV(2, 4, 4, 1, 1, "wide8w"); } else { ALLV(2, 4, 4, 0, 1, "wide8w"); }
             } else {
-                if (sh.gn) { RUN(v0, 1, 8, 4, 1, "v0 1x8"); RUN(sw, 1, 8, 4, 1, "nt 1x8 nontemporal"); }
-                else       { RUN(v0, 1, 8, 4, 0, "v0 1x8"); RUN(sw, 1, 8, 4, 0, "nt 1x8 nontemporal"); }
+                if (sh.gn) { RUNT(v0, 1, 8, 4, 1, 1, "1x8 mt4"); RUNT(v0, 1, 8, 8, 1, 1, "1x8 mt8"); RUNT(v0, 1, 4, 8, 1, 1, "1x4 mt8 (1 wave/SIMD)"); }
+                else       { RUNT(v0, 1, 8, 4, 0, 1, "1x8 mt4"); RUNT(v0, 1, 8, 8, 0, 1, "1x8 mt8"); RUNT(v0, 1, 4, 8, 0, 1, "1x4 mt8 (1 wave/SIMD)"); }
             }
             all.push_back(res);
         }
