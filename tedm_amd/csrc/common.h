@@ -101,6 +101,23 @@ TEDM_DEVFN uint4 split8_f16_res(const float (&v)[8], float (&lo)[8]) {
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
+// MODE.FP16_OVFL = 1 for the rest of this wave's kernel: float -> fp16 conversions saturate at +-65504 instead of producing
+// inf (probed on gfx950 with tools/ovfl_probe.hip: v_cvt_pk_f16_f32 honours it, the residual of a saturated value stays finite).
+TEDM_DEVFN void fp16_saturate_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+// split8_f16_res without the eight explicit clamps; the wave must have called fp16_saturate_on()
+TEDM_DEVFN uint4 split8_f16_res_sat(const float (&v)[8], float (&lo)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = v[2 * j], b = v[2 * j + 1];
+        unsigned hp;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * j]) : "v"(hp), "v"(v[2 * j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * j + 1]) : "v"(hp), "v"(v[2 * j + 1]));
+        w[j] = hp;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 TEDM_DEVFN float wave_sum(float v) {
 #pragma unroll

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     constexpr int NPB = F4 ? 3 : (PREC == TEDM_PREC_BF16 ? 1 : 2);   // weight fragments per (tile, chunk) [F4] / planes per 16-channel step
     constexpr int BUFSZ = REGION * NPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (F4) fp16_saturate_on();
 
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
                 unsigned e_v4, e_lo;
                 f4_scales(quad_max(m), e_v4, e_lo);
-                const uint4 hi = split8_f16_res(v, lo);
+                const uint4 hi = split8_f16_res_sat(v, lo);
                 char* rec = base + ((tid >> 2) + k * 64) * PSTRIDE;
                 *(uint4*)(rec + piece * 16) = hi;
                 *(unsigned*)(rec + 64 + piece * 4) = cvt8_fp4(lo, e_lo);
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* orec = smem + 2 * STG;                              // [4 heads][64 px] records of o (pixel stride 112 B: conflict-free reads)
     float2* lnx = (float2*)(orec + TP * 4 * PS);              // [64 px][2 cout halves] (sum, sumsq)
+    fp16_saturate_on();
     float* bgl = (float*)(lnx + TP * 2);                      // to_out bias [C], output LayerNorm gain [C], PreNorm gain [C]
 
     const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
         for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
         unsigned e_v4, e_lo;
         f4_scales(quad_max(m), e_v4, e_lo);
-        const uint4 hi = split8_f16_res(v, lo);
+        const uint4 hi = split8_f16_res_sat(v, lo);
         char* rec = smem + buf * STG + (tid >> 2) * PS;
         *(uint4*)(rec + piece * 16) = hi;
         *(unsigned*)(rec + 64 + piece * 4) = cvt8_fp4(lo, e_lo);
@@ -639,8 +641,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
                 float lo[4]; unsigned hw2[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float va = __builtin_amdgcn_fmed3f(ov[4 * g + 2 * c], -65504.f, 65504.f);
-                    const float vb = __builtin_amdgcn_fmed3f(ov[4 * g + 2 * c + 1], -65504.f, 65504.f);
+                    const float va = ov[4 * g + 2 * c], vb = ov[4 * g + 2 * c + 1];      // conversions saturate (fp16_saturate_on)
                     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hw2[c]) : "v"(va), "v"(vb));
                     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * c]) : "v"(hw2[c]), "v"(ov[4 * g + 2 * c]));
                     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * c + 1]) : "v"(hw2[c]), "v"(ov[4 * g + 2 * c + 1]));
