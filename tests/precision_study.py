@@ -150,5 +150,40 @@ def main():
         print(f'{s:14s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
 
 
-if __name__ == '__main__':
+
+
+def storage_study(size=64):
+    """What would 16-bit activation storage cost?  Every tensor the HIP path writes to HBM -- conv outputs, resnet-block
+    outputs, attention-block outputs -- is rounded to the storage format in the fp32 oracle (contractions: f16f4).
+    Run: python tests/precision_study.py storage [64|256]"""
+    gd = ROOT / 'tests' / 'golden'
+    g = np.load(gd / f'eps_d64_s{size}.npz')
+    shapes = {k: tuple(v) for k, v in json.loads((gd / 'unet_d64_state_dict_keys.json').read_text()).items()}
+    w = synth_state_dict(shapes, 0)
+    x_t, t = torch.from_numpy(g['x_t']), torch.from_numpy(g['t'])
+    ref = O.unet_forward(w, x_t, t)
+    res0, la0, fa0 = O.resnet_block, O.linear_attention, O.full_attention
+    for arith in ('fp32', 'f16f4'):
+        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('bf16', bf16)):
+            base = make_conv(arith) if arith != 'fp32' else _conv
+
+            def conv(x, ww, b=None, *a, _base=base, _rnd=rnd, **k):
+                y = _base(x, ww, b, *a, **k)
+                return y if y.shape[1] == 1 else _rnd(y)            # the 1-channel final conv is the fp32 result
+            F.conv2d = conv
+            O.resnet_block = lambda *a, _r=rnd, **k: _r(res0(*a, **k))
+            O.linear_attention = lambda *a, _r=rnd, **k: _r(la0(*a, **k))
+            O.full_attention = lambda *a, _r=rnd, **k: _r(fa0(*a, **k))
+            try:
+                eps = O.unet_forward(w, x_t, t)
+            finally:
+                F.conv2d = _conv
+                O.resnet_block, O.linear_attention, O.full_attention = res0, la0, fa0
+            print(f'contractions {arith:6s} storage {name:5s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'storage':
+    storage_study(int(sys.argv[2]) if len(sys.argv) > 2 else 64)
+    sys.exit(0)
+elif __name__ == '__main__':
     main()
