@@ -608,28 +608,32 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
 #pragma unroll
             for (int i = 1; i < 16; ++i) m = fmaxf(m, acc[mt][i]);
             m = fmaxf(m, __shfl_xor(m, 32));
+            // exp(q - m) = exp2(q log2e - m log2e): one FMA + v_exp_f32; the softmax normaliser and 32^-0.5 are per-pixel
+            // scalars and the pixel sits on the lane of the o accumulator, so they multiply the 16 outputs (together with
+            // 1/hw) instead of the 32 probabilities
+            const float ml = m * 1.44269504088896340736f;
             float q[16], sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { q[i] = __expf(acc[mt][i] - m); sum += q[i]; }
+            for (int i = 0; i < 16; ++i) { q[i] = __builtin_amdgcn_exp2f(fmaf(acc[mt][i], 1.44269504088896340736f, -ml)); sum += q[i]; }
             sum += __shfl_xor(sum, 32);
-            const float f = scale / sum;
+            const float f = scale * inv_hw / sum;
             f32x16 oacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                // q' (softmax probabilities x 32^-0.5, in [0, 0.18]) as ONE fp16 value: its rounding is independent across
-                // the 32 d of the sum; the context keeps hi + lo (it is one matrix per image and head, not noise)
+                // probabilities (in [0, 1]) as ONE fp16 value: the rounding is independent across the 32 d of the sum; the
+                // context keeps hi + lo (it is one matrix per image and head, not noise)
                 f16x8 qh;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) qh[j] = (_Float16)(q[8 * s + j] * f);
+                for (int j = 0; j < 8; ++j) qh[j] = (_Float16)q[8 * s + j];
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cth[s], qh, oacc, 0, 0, 0);
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ctl[s], qh, oacc, 0, 0, 0);
             }
             // lane (pixel r, half h) holds o[e], e = 8 g + 4 h + c: four groups of 4 consecutive channels
             float ov[16], om = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ov[i] = oacc[i] * inv_hw; om = fmaxf(om, fabsf(ov[i])); }
+            for (int i = 0; i < 16; ++i) { ov[i] = oacc[i] * f; om = fmaxf(om, fabsf(ov[i])); }
             om = fmaxf(om, __shfl_xor(om, 32));
             unsigned e_v4, e_lo;
             f4_scales(om, e_v4, e_lo);

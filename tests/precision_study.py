@@ -182,6 +182,45 @@ def storage_study(size=64):
             print(f'contractions {arith:6s} storage {name:5s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
 
 
+WHICH = None      # 'block1' / 'block2': round only that conv's output
+
+
+def branch_storage_study(size=64):
+    """16-bit storage of the BRANCH tensors only: the two conv outputs inside every ResnetBlock (consumed once, by the
+    GroupNorm prologue of the next kernel) -- the residual stream (block and attention outputs) stays fp32.
+    Run: python tests/precision_study.py branch [64|256]"""
+    gd = ROOT / 'tests' / 'golden'
+    g = np.load(gd / f'eps_d64_s{size}.npz')
+    shapes = {k: tuple(v) for k, v in json.loads((gd / 'unet_d64_state_dict_keys.json').read_text()).items()}
+    w = synth_state_dict(shapes, 0)
+    x_t, t = torch.from_numpy(g['x_t']), torch.from_numpy(g['t'])
+    ref = O.unet_forward(w, x_t, t)
+    block0 = O.block
+    for arith in ('fp32', 'f16f4'):
+        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('bf16', bf16)):
+            def blk(p, pre, x, groups, scale_shift, _rnd=rnd):
+                y = F.conv2d(x, p[pre + '.proj.weight'], p[pre + '.proj.bias'], padding=1)
+                if WHICH is None or pre.endswith(WHICH):
+                    y = _rnd(y)
+                y = F.group_norm(y, groups, p[pre + '.norm.weight'], p[pre + '.norm.bias'], eps=1e-5)
+                if scale_shift is not None:
+                    y = y * (scale_shift[0] + 1) + scale_shift[1]
+                return F.silu(y)
+            F.conv2d = make_conv(arith) if arith != 'fp32' else _conv
+            O.block = blk
+            try:
+                eps = O.unet_forward(w, x_t, t)
+            finally:
+                F.conv2d = _conv
+                O.block = block0
+            print(f'contractions {arith:6s} branch storage {name:5s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'branch':
+    if len(sys.argv) > 3:
+        WHICH = sys.argv[3]
+    branch_storage_study(int(sys.argv[2]) if len(sys.argv) > 2 else 64)
+    sys.exit(0)
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'storage':
     storage_study(int(sys.argv[2]) if len(sys.argv) > 2 else 64)
     sys.exit(0)
