@@ -20,6 +20,9 @@ extern "C" {
  *   stats: per-channel partial slab, mode 1: (B,E,Cout,2) sum/sumsq, mode 2: (B,E,Cout) max; E is
  *          returned in *stats_entries (and by tedm_op_conv2d_stats_entries).
  * Supported geometries: k=3 s=1 p=1 (optionally upsample), k=4 s=2 p=1, k=1 s=1 p=0.
+ * upsample: 0 none; 1 nearest x2 fused into the halo gather of the 3x3 kernel; 3 the same operator (Upsample,
+ *   models/unet_model.py:39-44) as four 2x2 parity convolutions on the low-resolution image with pre-summed taps -- the form
+ *   the UNet forward uses (one source, no statistics slab).
  * Synchronises the stream before returning (test helper). */
 int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int H, int W,
                    const float* weight_oihw, const float* bias, int Cout, int k, int stride, int upsample,
@@ -68,8 +71,10 @@ int tedm_op_full_attention_fwd_bwd(const float* qkv, const float* dout, int B, i
 int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* lnstats, const float* wqkv_oihw,
                           int B, long long hw, float* kmax_out, float* ctx_out, float* o_out, int prec, void* stream);
 
-/* Tuning knobs (benchmark harness): "conv_tile_wide" = 0|1|2 selects the workgroup tile used for
- * convolutions with >= 128 output channels (conv_igemm.hip). */
+/* Tuning knobs (benchmark harness / A-B tests; defaults are the product's): "conv_tile_wide", "conv_tile_wide256",
+ * "conv_tile_narrow" (workgroup tile per output-channel range), "conv_tpw_max", "conv_xcd_order", "conv_prio", "conv_solo"
+ * (conv_igemm.hip); "conv_up_split" 0|1 (Upsample as parity convolutions), "la_fused" 0|1|2, "la_tail" 0|1 (linear-attention
+ * sweeps, unet_host.hip); wgrad keys (wgrad.hip).  Unknown keys / values return TEDM_EINVAL. */
 int tedm_set_tuning(const char* key, int value);
 
 /* HIP-event profiler (bench.py's live roofline): brackets kernel launches on the launch stream with
