@@ -41,6 +41,9 @@ extern "C" {
 #define TEDM_PREC_F16F4    3   /* fp16 x fp16 MFMA + ONE block-scaled fp4 MFMA (K = 64) carrying both cross terms
                                   A_lo*B + A*B_lo of the fp16 split: 1.5 bf16-MFMA issues per 16 channels instead of 3;
                                   eps error ~2-3e-4 (inside the 1e-3 gate) */
+#define TEDM_PREC_FP16     4   /* ONE fp16 x fp16 MFMA per 16 channels (operand error 2^-12).  Not a whole-network mode (eps 9.5e-4):
+                                  F16F4 uses it for the k x k convolutions with >= 256 output channels, where it costs 1e-4 of
+                                  eps (tests/precision_study.py mixed256) and the matrix pipe / LDS / weight traffic fall by a third */
 
 /* forward flags */
 #define TEDM_FWD_TAPS_ONLY   (1 << 0)  /* skip ups[last][3], final_res_block, final_conv (feature extraction; eps_out may be NULL) */

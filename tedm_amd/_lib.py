@@ -13,6 +13,7 @@ LIB_PATH = _PKG / 'libtedm_hip.so'
 
 TEDM_MAX_LEVELS = 8
 PREC_BF16X3, PREC_BF16, PREC_FP16X2, PREC_F16F4 = 0, 1, 2, 3
+PREC_FP16 = 4          # one fp16 product: what f16f4 runs on the k x k convolutions with >= 256 output channels (not a network mode)
 FWD_TAPS_ONLY, FWD_TRACE, FWD_PREC_SHIFT = 1 << 0, 1 << 1, 8
 PREC_BY_NAME = {'bf16x3': PREC_BF16X3, 'bf16': PREC_BF16, 'fp16x2': PREC_FP16X2, 'f16f4': PREC_F16F4}
 

@@ -178,7 +178,7 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
 // ---- pack.hip -------------------------------------------------------------------------
 // Weight encodings (which packed layout a TEDM_PREC_* mode consumes): bf16 hi/lo planes, fp16 hi/lo planes, fp16 + fp4.
 enum { ENC_BF16 = 0, ENC_F16 = 1, ENC_F16F4 = 2 };
-inline int prec_encoding(int prec) { return prec == 2 /*FP16X2*/ ? ENC_F16 : (prec == 3 /*F16F4*/ ? ENC_F16F4 : ENC_BF16); }
+inline int prec_encoding(int prec) { return (prec == 2 /*FP16X2*/ || prec == 4 /*FP16*/) ? ENC_F16 : (prec == 3 /*F16F4*/ ? ENC_F16F4 : ENC_BF16); }
 int pack_conv_weights(const float* w, int Cout, int Cin, int KH, int KW, void* wpk, int enc, hipStream_t st);
 int pack_conv_weights_dgrad(const float* w, int Cout, int Cin, int KH, int KW, int ci0, int nci, void* wpk, int enc,
                             hipStream_t st);

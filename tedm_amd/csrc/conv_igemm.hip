@@ -9,6 +9,7 @@ int conv_launch_prec0(const ConvArgs& a, int KH, int stride, int ups, int pro, i
 int conv_launch_prec1(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
 int conv_launch_prec2(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
 int conv_launch_prec3(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
+int conv_launch_prec4(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
 
 int g_conv_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
 int g_conv_solo = 0;           // tedm_set_tuning("conv_solo", 1): pad the LDS request so that workgroups do not share a CU (diagnostic)
@@ -69,7 +70,7 @@ int conv_set_tuning(const char* key, int v) {
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
     const int id = select_tile_id(a.Cout, KH);
     const TileSel t = tile_geom(id, stride);
-    const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
+    const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
              ks, nbuf, pro, a.prec);
     if (ups == 3) snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-1,0,%d,%d,%d,%d,2,%d,%d>", t.wm, t.wn, t.mt, ks, pro, a.prec);
@@ -105,6 +106,10 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     a.nk16 = Cin / 16;
     if (a.prec == TEDM_PREC_BF16) return conv_launch_prec1(a, KH, stride, ups, pro, tile_id, st);
     if (a.prec == TEDM_PREC_FP16X2) return conv_launch_prec2(a, KH, stride, ups, pro, tile_id, st);
+    if (a.prec == TEDM_PREC_FP16) {
+        if (Cin % 32 || a.C1 % 32) return TEDM_EINVAL;            // 32-channel chunks
+        return conv_launch_prec4(a, KH, stride, ups, pro, tile_id, st);
+    }
     if (a.prec == TEDM_PREC_F16F4) {
         if (Cin % 32 || a.C1 % 32) return TEDM_EINVAL;            // 32-channel blocks must not straddle the two sources
         return conv_launch_prec3(a, KH, stride, ups, pro, tile_id, st);

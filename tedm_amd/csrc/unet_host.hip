@@ -177,6 +177,8 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
+int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1) BEFORE tedm_unet_pack: under F16F4 the k x k convolutions with >= 256 output
+                           // channels run one fp16 product (TEDM_PREC_FP16; eps +1e-4, tests/precision_study.py mixed256)
 int g_conv_up_split = 1;   // tedm_set_tuning("conv_up_split", 0|1): Upsample as four 2x2 parity convs on the low-resolution image
 int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
@@ -329,7 +331,12 @@ int build_plan(tedm_unet* u) {
 
 // Arithmetic mode of one conv launch: the handle's mode, except that a weight kept in bf16 planes under F16F4 (the
 // LinearAttention to_qkv, shared with linattn_fused.hip) runs bf16x3.
-inline int conv_prec(const ConvW& w, int prec) { return (prec == TEDM_PREC_F16F4 && w.enc == ENC_BF16) ? TEDM_PREC_BF16X3 : prec; }
+// The kernel arithmetic follows the encoding a weight was packed in: under F16F4 the deep k x k convolutions carry fp16 planes
+// (tedm_unet_pack) and run ONE fp16 product (TEDM_PREC_FP16).
+inline int conv_prec(const ConvW& w, int prec) {
+    if (prec != TEDM_PREC_F16F4) return prec;
+    return w.enc == ENC_BF16 ? TEDM_PREC_BF16X3 : (w.enc == ENC_F16 ? TEDM_PREC_FP16 : prec);
+}
 inline int la_prec(int prec) { return prec; }    // linattn_fused.hip consumes every weight encoding
 inline bool prec_ok(int prec) { return prec == TEDM_PREC_BF16X3 || prec == TEDM_PREC_BF16 || prec == TEDM_PREC_FP16X2 || prec == TEDM_PREC_F16F4; }
 
@@ -673,6 +680,7 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
     for (ConvW* c : h->convs) {
         c->enc = prec_encoding(h->prec);
+        if (h->prec == TEDM_PREC_F16F4 && g_deep_fp16 && c->k > 1 && c->cout >= 256 && !c->la_qkv) c->enc = ENC_F16;
         CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, c->enc, st));
         if (c->up2) {
             const size_t ps = conv_packed_bytes(c->cout, c->cin, 4), wb = (size_t)16 * c->cout * c->cin * 4;
@@ -1056,6 +1064,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
     if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
+    if (!strcmp(key, "deep_fp16") && (value == 0 || value == 1)) { g_deep_fp16 = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);

@@ -89,6 +89,17 @@ def make_conv(scheme):
         if x.shape[1] == 1:                      # the stem runs on the exact-fp32 MFMA
             return _conv(x, w, b, stride, padding, *a, **k)
         c = lambda xx, ww: _conv(xx, ww, None, stride, padding, *a, **k)
+        if scheme.startswith('mixed'):
+            # mixed<N>[h]: single fp16 product for convs with >= N output channels, f16f4 below
+            # ('h': fp16 x (fp16 hi + lo) weights, i.e. only the ACTIVATION is rounded once)
+            thr = int(''.join(ch for ch in scheme[5:] if ch.isdigit()))
+            if w.shape[0] >= thr and w.shape[2] > 1:
+                if scheme.endswith('h'):
+                    y = c(fp16(x), w)
+                else:
+                    y = c(fp16(x), fp16(w))
+                return y if b is None else y + b.reshape(1, -1, 1, 1)
+            return make_conv('f16f4')(x, w, b, stride, padding, *a, **k)
         if scheme == 'bf16':
             y = c(bf16(x), bf16(w))
         elif scheme == 'fp16':
