@@ -344,7 +344,8 @@ def main() -> None:
                                  'bf16': 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM',
                                  'fp16x2': 'fp16 activations x fp16 hi/lo weights (2 products), fp32 accumulate, fp32 activations in HBM',
                                  'f16f4': 'fp16 x fp16 MFMA + one block-scaled fp4 MFMA (K=64) carrying both cross terms of the fp16 split: '
-                                          '1.5 bf16-rate MFMA issues per 16 channels, fp32 accumulate, fp32 activations in HBM'}[args.prec],
+                                          '1.5 bf16-rate MFMA issues per 16 channels; the k x k convolutions with >= 256 output channels run '
+                                          'one fp16 product; fp32 accumulate, fp32 activations in HBM'}[args.prec],
                    'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
     }
 
@@ -360,7 +361,11 @@ def main() -> None:
             t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), byts / (PEAK_HBM_GBS * 1e9)
             hbm_bound = t_hbm > t_mfma
             gbs = byts / (ms * 1e-3) / 1e9
-            mp = {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec]
+            def products_of(kernel_name):       # MFMA issues per algorithmic product: last template argument = TEDM_PREC_*
+                import re
+                m_ = re.search(r',(\d)>$', kernel_name)
+                return {0: 3, 1: 1, 2: 2, 3: 1.5, 4: 1}[int(m_.group(1))] if m_ else {'bf16x3': 3, 'fp16x2': 2, 'bf16': 1, 'f16f4': 1.5}[args.prec]
+            mp = products_of(name)
             out['roofline'] = {
                 'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': name,
                 'achieved': round(gbs if hbm_bound else achieved, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
@@ -385,7 +390,8 @@ def main() -> None:
                 if fl / (PEAK_BF16_TFLOPS * 1e12) >= by / (PEAK_HBM_GBS * 1e9):
                     out['roofline']['mfma_bound_kernel'] = {'kernel': nm, 'alg_tflops': round(fl / (m_ * 1e-3) / 1e12, 2),
                                                            'frac': round(fl / (m_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                                           'avg_us': round(1e3 * m_ / ln, 2), 'from': 'untimed profiled step'}
+                                                           'avg_us': round(1e3 * m_ / ln, 2), 'mfma_products': products_of(nm),
+                                                           'from': 'untimed profiled step'}
                     break
         per_img = elapsed / (B * K)
         scale = (S / 256.0) ** 2
