@@ -89,6 +89,21 @@ def make_conv(scheme):
         if x.shape[1] == 1:                      # the stem runs on the exact-fp32 MFMA
             return _conv(x, w, b, stride, padding, *a, **k)
         c = lambda xx, ww: _conv(xx, ww, None, stride, padding, *a, **k)
+        if scheme.startswith('only'):
+            # only<S>[c1|c2]: single fp16 product on the k x k convs whose OUTPUT is S pixels wide (one resolution level of the
+            # 64x64 study input: 64, 32, 16, 8), f16f4 elsewhere; c1 / c2: only convs WITHOUT / WITH a GroupNorm'd input
+            # (told apart by the input statistics is not possible here: c1 = Cin != Cout or first-in-block is approximated by
+            # "input is not post-SiLU", i.e. its minimum is below -0.3)
+            S_ = int(''.join(ch for ch in scheme[4:] if ch.isdigit()))
+            sel = w.shape[2] > 1 and (x.shape[-1] // (stride if isinstance(stride, int) else stride[0])) == S_
+            if sel and scheme.endswith('c1'):
+                sel = float(x.min()) < -0.3
+            if sel and scheme.endswith('c2'):
+                sel = float(x.min()) >= -0.3
+            if sel:
+                y = c(fp16(x), fp16(w))
+                return y if b is None else y + b.reshape(1, -1, 1, 1)
+            return make_conv('f16f4')(x, w, b, stride, padding, *a, **k)
         if scheme.startswith('mixed'):
             # mixed<N>[h]: single fp16 product for convs with >= N output channels, f16f4 below
             # ('h': fp16 x (fp16 hi + lo) weights, i.e. only the ACTIVATION is rounded once)
