@@ -12,7 +12,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // v * sigmoid(v).  v_rcp_f32 (1 ulp) instead of the IEEE divide: `a / b` expands to an 11-instruction div_scale / fma /
 // div_fixup sequence, which tripled the VALU cost of every GroupNorm+SiLU prologue.
-TEDM_DEVFN float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// The four operations are pinned (no contraction, no re-association): two inlined copies of a staging loop must round every
+// element identically, or a tile staged by the loop prologue and the same tile staged inside the loop differ in the last bit
+// -- and with 11-bit operands (TEDM_PREC_FP16) such a bit flips output roundings, i.e. results would depend on how tiles
+// are grouped into workgroups (on the batch size).
+TEDM_DEVFN float silu_f(float v) {
+    float t, e, d, rcp, y;
+    asm("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(t) : "v"(v));           // -log2(e) * v
+    asm("v_exp_f32 %0, %1" : "=v"(e) : "v"(t));
+    asm("v_add_f32 %0, 1.0, %1" : "=v"(d) : "v"(e));
+    asm("v_rcp_f32 %0, %1" : "=v"(rcp) : "v"(d));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(y) : "v"(v), "v"(rcp));
+    return y;
+}
 
 // Split 8 fp32 values into bf16 hi (round-to-nearest) and bf16 lo = bf16(v - hi): hi + lo carries
 // ~16 significand bits, so A_hi*B_hi + A_lo*B_hi + A_hi*B_lo reproduces an fp32 product to ~2^-17.

@@ -177,8 +177,11 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
-int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1) BEFORE tedm_unet_pack: under F16F4 the k x k convolutions with >= 256 output
-                           // channels run one fp16 product (TEDM_PREC_FP16; eps +1e-4, tests/precision_study.py mixed256)
+int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1|2) BEFORE tedm_unet_pack: which convolutions run ONE fp16 product under
+                           // F16F4 (TEDM_PREC_FP16).  1 (default): the two 3x3 convs inside every ResnetBlock below the full
+                           // resolution (GroupNorm renormalises their output; per-conv eps cost 0.2-1e-4, tests/precision_study.py
+                           // idx<N>); the convs ON the residual stream (Downsample / Upsample / last-level convs: 1-3e-4 each) and
+                           // the full-resolution level keep the fp4 cross terms.  2: every k x k conv with >= 256 output channels.
 int g_conv_up_split = 1;   // tedm_set_tuning("conv_up_split", 0|1): Upsample as four 2x2 parity convs on the low-resolution image
 int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
@@ -680,7 +683,12 @@ int tedm_unet_pack(tedm_unet* h, void* stream) {
         return fail(TEDM_ENOMEM, "hipMalloc for FiLM bias failed");
     for (ConvW* c : h->convs) {
         c->enc = prec_encoding(h->prec);
-        if (h->prec == TEDM_PREC_F16F4 && g_deep_fp16 && c->k > 1 && c->cout >= 256 && !c->la_qkv) c->enc = ENC_F16;
+        if (h->prec == TEDM_PREC_F16F4 && c->k > 1 && !c->la_qkv) {
+            const std::string top = "ups." + std::to_string(h->nres - 1) + ".";
+            const bool in_block = c->key.find(".block1.proj") != std::string::npos || c->key.find(".block2.proj") != std::string::npos;
+            const bool full_res = c->key.rfind("downs.0.", 0) == 0 || c->key.rfind(top, 0) == 0 || c->key.rfind("final_res_block", 0) == 0;
+            if ((g_deep_fp16 == 1 && in_block && !full_res) || (g_deep_fp16 == 2 && c->cout >= 256)) c->enc = ENC_F16;
+        }
         CHECK(pack_conv_weights(h->P(c->key + ".weight"), c->cout, c->cin, c->k, c->k, c->wpk, c->enc, st));
         if (c->up2) {
             const size_t ps = conv_packed_bytes(c->cout, c->cin, 4), wb = (size_t)16 * c->cout * c->cin * 4;
@@ -1064,7 +1072,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
     if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
-    if (!strcmp(key, "deep_fp16") && (value == 0 || value == 1)) { g_deep_fp16 = value; return TEDM_OK; }
+    if (!strcmp(key, "deep_fp16") && value >= 0 && value <= 2) { g_deep_fp16 = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);

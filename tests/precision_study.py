@@ -18,6 +18,7 @@ from oracle import unet_ref as O                     # noqa: E402
 from tedm_amd.weights import synth_state_dict        # noqa: E402
 
 _conv = F.conv2d
+CALLS = []
 
 
 def bf16(x): return x.to(torch.bfloat16).float()
@@ -89,6 +90,26 @@ def make_conv(scheme):
         if x.shape[1] == 1:                      # the stem runs on the exact-fp32 MFMA
             return _conv(x, w, b, stride, padding, *a, **k)
         c = lambda xx, ww: _conv(xx, ww, None, stride, padding, *a, **k)
+        if scheme.startswith('set:'):
+            # set:<i,j,k-l,...>: single fp16 product on those k x k convolutions (call order), f16f4 elsewhere
+            if w.shape[2] > 1:
+                CALLS.append((x.shape[1], w.shape[0], x.shape[-1], w.shape[2]))
+                idx, sel = len(CALLS) - 1, False
+                for part in scheme[4:].split(','):
+                    lo, _, hi = part.partition('-')
+                    sel |= int(lo) <= idx <= int(hi or lo)
+                if sel:
+                    y = c(fp16(x), fp16(w))
+                    return y if b is None else y + b.reshape(1, -1, 1, 1)
+            return make_conv('f16f4')(x, w, b, stride, padding, *a, **k)
+        if scheme.startswith('idx'):
+            # idx<N>: single fp16 product on the N-th k x k convolution in call order only (CALLS counts them), f16f4 elsewhere
+            if w.shape[2] > 1:
+                CALLS.append((x.shape[1], w.shape[0], x.shape[-1], w.shape[2]))
+                if len(CALLS) - 1 == int(scheme[3:]):
+                    y = c(fp16(x), fp16(w))
+                    return y if b is None else y + b.reshape(1, -1, 1, 1)
+            return make_conv('f16f4')(x, w, b, stride, padding, *a, **k)
         if scheme.startswith('only'):
             # only<S>[c1|c2]: single fp16 product on the k x k convs whose OUTPUT is S pixels wide (one resolution level of the
             # 64x64 study input: 64, 32, 16, 8), f16f4 elsewhere; c1 / c2: only convs WITHOUT / WITH a GroupNorm'd input
@@ -173,7 +194,11 @@ def main():
             eps = O.unet_forward(w, x_t, t)
         finally:
             F.conv2d = _conv
-        print(f'{s:14s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}', flush=True)
+        extra = ''
+        if s.startswith('idx') and int(s[3:]) < len(CALLS):
+            extra = '  conv (Cin, Cout, width, k) = %s of %d' % (CALLS[int(s[3:])], len(CALLS))
+        CALLS.clear()
+        print(f'{s:14s} eps rel-L2 = {float((eps - ref).norm() / ref.norm()):.3e}{extra}', flush=True)
 
 
 
