@@ -13,4 +13,14 @@ from .diffusion import DiffusionModel       # noqa: F401
 from .dataset_dm import DatasetDM           # noqa: F401
 from .weights import load_synth_weights, synth_state_dict   # noqa: F401
 
-__all__ = ['Unet', 'DiffusionModel', 'DatasetDM', 'load_synth_weights', 'synth_state_dict']
+
+
+def set_tuning(key: str, value: int) -> None:
+    """Library-wide tuning knob (include/tedm_hip_ops.h: tedm_set_tuning), e.g. `set_tuning('deep_fp16', 0)` keeps the fp4 cross
+    terms on every convolution of the f16f4 mode.  Keys that change how weights are PACKED (deep_fp16) take effect at the next
+    pack: call `Unet.invalidate_packed()` on live modules."""
+    from . import _lib
+    _lib.check(_lib.lib().tedm_set_tuning(key.encode(), int(value)), f'tedm_set_tuning({key!r}, {value})')
+
+
+__all__ = ['Unet', 'DiffusionModel', 'DatasetDM', 'load_synth_weights', 'synth_state_dict', 'set_tuning']
