@@ -90,6 +90,15 @@ def make_conv(scheme):
         if x.shape[1] == 1:                      # the stem runs on the exact-fp32 MFMA
             return _conv(x, w, b, stride, padding, *a, **k)
         c = lambda xx, ww: _conv(xx, ww, None, stride, padding, *a, **k)
+        if scheme.startswith('la16'):
+            # la16[q|o]: single fp16 product on the linear-attention projections (to_qkv: 384 outputs; to_out: 128 inputs, 1x1),
+            # the product set of the k x k convs (ResnetBlock-internal below full resolution) otherwise
+            is_q = w.shape[2] == 1 and w.shape[0] == 384
+            is_o = w.shape[2] == 1 and w.shape[1] == 128 and w.shape[0] != 384
+            if (is_q and not scheme.endswith('o')) or (is_o and not scheme.endswith('q')):
+                y = c(fp16(x), fp16(w))
+                return y if b is None else y + b.reshape(1, -1, 1, 1)
+            return make_conv('set:5-8,10-13,15-18,20-27,29-32,34-37')(x, w, b, stride, padding, *a, **k)
         if scheme.startswith('set:'):
             # set:<i,j,k-l,...>: single fp16 product on those k x k convolutions (call order), f16f4 elsewhere
             if w.shape[2] > 1:
