@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """How much margin does the eps gate (1e-3 rel-L2 vs the CPU fp32 reference) have over inputs?  Per-sample eps error of the default
 arithmetic on 256x256 images for several seeds at the extreme and at random timesteps: the SAME noised x_t (oracle q-sample) goes
-through the HIP UNet and through the CPU oracle (test infrastructure).
-usage (GPU box): python tools/eps_margin.py [n_batches] > profiles/<tag>_eps_margin.txt"""
+through the HIP UNet and through the CPU oracle (test infrastructure: lives under tests/ because it imports the oracle).
+usage (GPU box): python tests/eps_margin.py [n_batches] > profiles/<tag>_eps_margin.txt"""
 import os
 import sys
 
