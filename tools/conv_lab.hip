@@ -13,7 +13,11 @@
 #include <math.h>
 #include <type_traits>
 #define CONV_NO_LAUNCHERS
-#define CONV_PREC 3
+// -DLAB_PREC=4 measures the single-fp16-product instances (weights packed as fp16 planes)
+#ifndef LAB_PREC
+#define LAB_PREC 3
+#endif
+#define CONV_PREC LAB_PREC
 #include "common.h"
 #include "../../include/tedm_hip.h"
 #include "pack.hip"
@@ -65,13 +69,13 @@ static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int
 #define RUN(NS, WM, WN, MT, PRO, LABEL) RUNT(NS, WM, WN, MT, PRO, 1, LABEL)
 #define RUNT(NS, WM, WN, MT, PRO, TPW, LABEL)                                                                              \
     do {                                                                                                             \
-        using G = NS::Geo<3, 3, 1, WM, MT, 2, 2, 3, WM * WN * 64>;                                                   \
+        using G = NS::Geo<3, 3, 1, WM, MT, 2, 2, LAB_PREC, WM * WN * 64>;                                                   \
         ConvArgs b = a;                                                                                              \
         const int TR = WM * MT;                                                                                      \
         b.tiles_y = (b.Ho + TR - 1) / TR; b.tiles_x = (b.Wo + 31) / 32;                                              \
         b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = TPW; b.xcd_order = 1;                                     \
         const int grid = ((b.B * b.tiles_x * b.tiles_y + TPW - 1) / TPW) * b.ny;                                                  \
-        const float ms = time_kernel(NS::conv_igemm_kernel<3, 3, 1, 1, 0, WM, WN, MT, 2, 2, PRO, 3>, b, WM * WN * 64, \
+        const float ms = time_kernel(NS::conv_igemm_kernel<3, 3, 1, 1, 0, WM, WN, MT, 2, 2, PRO, LAB_PREC>, b, WM * WN * 64, \
                                      (size_t)G::LDS, grid, iters);                                                   \
         res.push_back({LABEL, ms});                                                                                  \
     } while (0)
@@ -126,10 +130,10 @@ int main(int argc, char** argv) {
             fill(w, (size_t)sh.Cout * Cin * 9, 1.f / sqrtf(Cin * 9.f)); fill(bias, sh.Cout, 0.1f);
             fill(ga, (size_t)B * Cin, 0.1f); fill(gb, (size_t)B * Cin, 0.1f);
         }
-        if (pack_conv_weights(w, sh.Cout, Cin, sh.k, sh.k, wpk, ENC_F16F4, 0) != 0) { printf("pack failed\n"); return 1; }
+        if (pack_conv_weights(w, sh.Cout, Cin, sh.k, sh.k, wpk, (LAB_PREC == 4 ? ENC_F16 : ENC_F16F4), 0) != 0) { printf("pack failed\n"); return 1; }
         ConvArgs a{};
         a.x1 = x1; a.C1 = sh.C1; a.x2 = x2; a.C2 = sh.C2; a.B = B; a.H = sh.S; a.W = sh.S; a.Ho = sh.S; a.Wo = sh.S; a.Cout = sh.Cout;
-        a.wpk = wpk; a.bias = bias; a.out = out; a.stats = stats; a.stats_mode = STATS_SUMSQ; a.nk16 = Cin / 16; a.prec = 3;
+        a.wpk = wpk; a.bias = bias; a.out = out; a.stats = stats; a.stats_mode = STATS_SUMSQ; a.nk16 = Cin / 16; a.prec = LAB_PREC;
         if (sh.gn) { a.pro_a = ga; a.pro_b = gb; }
         const double flops = 2.0 * B * sh.S * sh.S * sh.Cout * Cin * T;
         std::vector<std::vector<Res>> all;
