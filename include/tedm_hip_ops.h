@@ -74,7 +74,9 @@ int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* ln
 /* Tuning knobs (benchmark harness / A-B tests; defaults are the product's): "conv_tile_wide", "conv_tile_wide256",
  * "conv_tile_narrow" (workgroup tile per output-channel range), "conv_tpw_max", "conv_xcd_order", "conv_prio", "conv_solo"
  * (conv_igemm.hip); "conv_up_split" 0|1 (Upsample as parity convolutions), "la_fused" 0|1|2, "la_tail" 0|1 (linear-attention
- * sweeps, unet_host.hip); wgrad keys (wgrad.hip).  Unknown keys / values return TEDM_EINVAL. */
+ * sweeps, unet_host.hip); "deep_fp16" 0|1|2 (which convolutions run one fp16 product under TEDM_PREC_F16F4: none | the 3x3 convs
+ * inside the ResnetBlocks below full resolution (default) | every k x k conv with >= 256 output channels; read by tedm_unet_pack,
+ * so set it before packing); wgrad keys (wgrad.hip).  Unknown keys / values return TEDM_EINVAL. */
 int tedm_set_tuning(const char* key, int value);
 
 /* HIP-event profiler (bench.py's live roofline): brackets kernel launches on the launch stream with
