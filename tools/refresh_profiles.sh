@@ -25,4 +25,6 @@ python tools/conv_shape_profile.py > profiles/${tag}_conv_shape_profile.txt 2>/d
 # per-dispatch timeline of one forward step (every kernel in launch order)
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/trace_one_step.py gpurun_out/${tag}_trace > profiles/${tag}_step_timeline.txt
+# eps error over seeds / timesteps against the CPU oracle (test infrastructure)
+python tests/eps_margin.py 4 2>/dev/null > profiles/${tag}_eps_margin.txt
 echo "profiles/${tag}_* written"
