@@ -53,6 +53,21 @@ inline TileSel tile_geom(int id, int stride) {
     return t;
 }
 
+int g_conv_small_grid = 1;   // tedm_set_tuning("conv_small_grid", 0|1)
+
+// Small batches (the sampler, single images): when the default tile would launch fewer workgroups than the chip has CUs, halve the
+// output channels per workgroup (same rows per tile, hence the same statistics slab and -- every output accumulates its taps and
+// channel chunks in the same order whatever shares its workgroup -- the same bits).
+inline int effective_tile(const ConvArgs& a, int KH, int stride, int ups) {
+    int id = select_tile_id(a.Cout, KH);
+    if (!g_conv_small_grid) return id;
+    const TileSel t = tile_geom(id, stride);
+    const int TR = t.wm * t.mt, Ho = ups == 3 ? a.H : a.Ho, Wo = ups == 3 ? a.W : a.Wo;
+    const long long wgs = (long long)a.B * ((Ho + TR - 1) / TR) * ((Wo + 31) / 32) * (ups == 3 ? 4 : 1) * (((a.Cout + 31) / 32 + t.wn - 1) / t.wn);
+    if (wgs < 256) { if (id == 4) id = 2; else if (id == 3) id = 1; }
+    return id;
+}
+
 }  // namespace
 
 int conv_set_tuning(const char* key, int v) {
@@ -63,12 +78,13 @@ int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_conv_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_conv_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_small_grid") && (v == 0 || v == 1)) { g_conv_small_grid = v; return TEDM_OK; }
     return TEDM_EINVAL;
 }
 
 // Label == the rocprof kernel symbol (template argument list of conv_igemm_kernel).
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
-    const int id = select_tile_id(a.Cout, KH);
+    const int id = effective_tile(a, KH, stride, ups);
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
@@ -93,7 +109,7 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 || a.C1 % 16 || (a.x2 && a.C2 % 16)) return TEDM_EINVAL;
     if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
-    const int tile_id = select_tile_id(a.Cout, KH);
+    const int tile_id = effective_tile(a, KH, stride, ups);
     const TileSel t = tile_geom(tile_id, stride);
     const int TR = t.wm * t.mt;
     if (ups == 3) {                                               // parity convs: the kernel's grid is the low-resolution one
