@@ -103,12 +103,13 @@ def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):
 
 def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
     """BASELINE config 4: one optimizer step of trainers/train_base_diffusion.py:36-47 per GPU-local batch
-    (q-sample, recorded UNet forward, L1/p2 loss, full backward as HIP kernels), ONE all-reduce of the flat
-    gradient buffer (RCCL) and a fused Adam update.  Weak scaling: B images per GPU."""
+    (q-sample, recorded UNet forward, L1/p2 loss, full backward as HIP kernels), the all-reduce of the flat gradient
+    buffer (RCCL) in `--buckets` slices launched on a side stream as the backward completes them, and a fused Adam update.
+    Weak scaling: B images per GPU."""
     import torch
     dm.train()
     opt = torch.optim.Adam(dm.model.parameters(), lr=1e-4, fused=True)
-    tr = dp.DataParallelTrainer(dm, opt, dist)
+    tr = dp.DataParallelTrainer(dm, opt, dist, n_buckets=args.buckets)
     B, S = x0.shape[0], x0.shape[-1]
 
     def step():
@@ -121,7 +122,7 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
             'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
             'config': {'workload': f'DiffusionModel.train_step + backward + Adam, {B}x1x{S}x{S} per GPU, global batch {B * world} '
-                                   f'(BASELINE configs[3])', 'final_loss': round(float(loss), 6),
+                                   f'(BASELINE configs[3])', 'final_loss': round(float(loss), 6), 'grad_allreduce_buckets': args.buckets if dist is not None else 0,
                        'train_workspace_GiB': round(dm.model._train_ws.numel() / 2 ** 30, 2)}}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -129,37 +130,38 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
 
 
 def bench_tedm(args, dm, dp, dist, dev, world, rank):
-    """BASELINE config 5 shape: TEDM = frozen diffusion UNet + pixel-classifier head trained with BCE
-    (trainers/train_datasetDM.py), JSRT-shaped synthetic data (B,1,128,128) + binary masks, the 8 TEDM timesteps
-    (train.py:47).  One step = T UNet forwards (taps only) + head forward/backward + Adam on the head; the head's first
-    layer runs fused at the taps' native resolution (tedm_amd/head.py).  The unfused reference formulation
-    (materialised (B, 960*T, S, S) features) is timed next to it."""
+    """BASELINE config 5 shape: TEDM = frozen diffusion UNet + SHARED-WEIGHTS pixel classifier (trainers/train_datasetDM.py:30-42)
+    trained with BCE on replicated targets (trainers/train_baseline.py:30,44), JSRT-shaped synthetic data (B,1,128,128) + binary
+    masks, the 8 TEDM timesteps (train.py:47).  One step = B*8 UNet forwards (taps only, one native batch in '(b step)' order)
+    + head forward/backward + Adam on the head; the head's 960 -> 128 projection runs fused at the taps' native resolution
+    (tedm_amd/head.py), once per tap with the same weights for every timestep.  The unfused reference formulation
+    (materialised (B, 960*8, S, S) features, regrouped to (B*8, 960, S, S)) and the inference call (`tedm.predict`: mean over
+    timesteps of the sigmoids > .5, app.py:62-79) are timed next to it."""
     import torch
-    import torch.nn.functional as F
-    from tedm_amd import DatasetDM, load_synth_weights
+    from tedm_amd import DatasetDM, load_synth_weights, tedm
     steps = [1, 10, 25, 50, 200, 400, 600, 800]
     B, S = args.batch, 128
     ddm = DatasetDM(Namespace(normalize=True, dim=64, saved_diffusion_model='/nonexistent', verbose=False, device='cuda',
-                              t_steps_to_save=steps, max_images_per_forward=64))
+                              t_steps_to_save=steps, max_images_per_forward=256, shared_weights_over_timesteps=True))
     ddm.diffusion_model = dm
     load_synth_weights(ddm.classifier, seed=5)
     ddm = ddm.to(dev).train()
     dm.eval()
+    T = len(steps)
     g = torch.Generator().manual_seed(99 + rank)
     x = torch.rand(B, 1, S, S, generator=g).to(dev)
     yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing='ij')
     mask = ((((yy - 64) / 40.) ** 2 + ((xx - 40) / 22.) ** 2 < 1) | (((yy - 64) / 40.) ** 2 + ((xx - 88) / 22.) ** 2 < 1)).float()
     y = mask[None, None].expand(B, 1, S, S).contiguous().to(dev)                 # two blobs, like a lung mask
-    opt = torch.optim.Adam(ddm.classifier.parameters(), lr=1e-4)
+    y_rep = tedm.replicate_targets(y, T)
+    head = list(ddm.classifier.parameters())
+    opt = torch.optim.Adam(head, lr=1e-4)
 
     def step():
         opt.zero_grad()
-        loss = F.binary_cross_entropy_with_logits(ddm(x), y)
+        loss, _ = tedm.bce_loss(ddm(x), y_rep)
         loss.backward()
-        if dist is not None:
-            for p in ddm.classifier.parameters():
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                p.grad.div_(world)
+        tedm.allreduce_head_grads_(dist, head)
         opt.step()
         return loss.detach()
     res = {}
@@ -168,17 +170,25 @@ def bench_tedm(args, dm, dp, dist, dev, world, rank):
         torch.cuda.reset_peak_memory_stats(dev)
         elapsed, loss = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
         res[fused] = (elapsed, float(loss), torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+    ddm.eval()
+    with torch.no_grad():
+        infer_s, (prob, m) = dp.timed_steps(lambda: tedm.predict(ddm, x), args.steps, args.warmup, dist, dev)
+    dice = float(tedm.dice(m, y).nanmean())
     if rank == 0:
         el, loss, mem = res[True]
         print(json.dumps({
-            'metric': 'TEDM head train-step images/sec @128x128, 8 timesteps (frozen UNet x8 + fused head fwd/bwd + Adam)',
+            'metric': 'TEDM head train-step images/sec @128x128, 8 timesteps (frozen UNet x8 + shared-weights head fwd/bwd + Adam)',
             'value': round(world * B * args.steps / el, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * el / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
-            'config': {'workload': f'DatasetDM (TEDM) train step, {B}x1x{S}x{S} per GPU, t_steps={steps} (BASELINE configs[4] shape)',
+            'config': {'workload': f'DatasetDM + shared-weights classifier (TEDM) train step, {B}x1x{S}x{S} per GPU, t_steps={steps} '
+                                   f'(BASELINE configs[4] shape)', 'unet_forwards_per_step': B * T,
                        'final_loss': round(loss, 6), 'peak_mem_GiB': round(mem, 2),
                        'unfused_ms_per_step': round(1e3 * res[False][0] / args.steps, 3),
-                       'unfused_peak_mem_GiB': round(res[False][2], 2)}}), flush=True)
+                       'unfused_peak_mem_GiB': round(res[False][2], 2),
+                       'predict_ms_per_batch': round(1e3 * infer_s / args.steps, 3),
+                       'predict_images_per_s': round(world * B * args.steps / infer_s, 2), 'dice_of_the_briefly_trained_head': round(dice, 4)}}),
+              flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -224,10 +234,11 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC'), choices=['bf16x3', 'bf16', 'fp16x2', 'f16f4'],
-                    help="arithmetic mode of the MFMA contractions; default: the product's (f16f4 for inference, bf16x3 for --mode train)")
+                    help="arithmetic mode of the MFMA contractions; default: f16f4 (the library's opt-in fast inference mode; the module default is bf16x3), bf16x3 for --mode train")
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--buckets', type=int, default=4, help='--mode train: gradient all-reduce buckets launched under the backward (1 = one all-reduce after it)')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
     ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
     ap.add_argument('--tile-narrow', type=int, default=None, help='tuning: conv tile id for Cout<128')
@@ -266,13 +277,17 @@ def main() -> None:
     dm = DiffusionModel(cfg)
     load_synth_weights(dm.model, seed=0)
     dm = dm.to(dev).eval()
-    if args.prec is None:
-        args.prec = dm.model.train_precision if args.mode == 'train' else dm.model.precision
+    if args.prec is None:          # the benchmark opts into the fast inference arithmetic (gated by the eps check below); training: bf16x3
+        args.prec = dm.model.train_precision if args.mode == 'train' else 'f16f4'
     dm.model.precision = dm.model.train_precision = args.prec
 
     g = torch.Generator().manual_seed(1234 + rank)
     x0 = torch.rand(B, 1, S, S, generator=g).to(dev)
-    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    t[0] = 0                       # the measured worst case of the eps error (profiles/*eps_margin.txt) is always in the checked batch
+    if B > 1:
+        t[1] = 999
+    t = t.to(dev)
     noise = torch.randn(B, 1, S, S, generator=g).to(dev)
 
     def step():
@@ -344,8 +359,9 @@ def main() -> None:
                                  'bf16': 'bf16 MFMA, fp32 accumulate, fp32 activations in HBM',
                                  'fp16x2': 'fp16 activations x fp16 hi/lo weights (2 products), fp32 accumulate, fp32 activations in HBM',
                                  'f16f4': 'fp16 x fp16 MFMA + one block-scaled fp4 MFMA (K=64) carrying both cross terms of the fp16 split: '
-                                          '1.5 bf16-rate MFMA issues per 16 channels; the k x k convolutions with >= 256 output channels run '
-                                          'one fp16 product; fp32 accumulate, fp32 activations in HBM'}[args.prec],
+                                          '1.5 bf16-rate MFMA issues per 16 channels; the two 3x3 convolutions INSIDE every ResnetBlock below the full '
+                                          'resolution (downs.1-3, mid, ups.0-2: 28 of the 46 k x k convolutions) run one fp16 product; '
+                                          'fp32 accumulate, fp32 activations in HBM'}[args.prec],
                    'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
     }
 
@@ -371,6 +387,11 @@ def main() -> None:
                 'achieved': round(gbs if hbm_bound else achieved, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                 'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(name),
+                # `achieved`/`frac` of an HBM-bound kernel count the bytes of THIS build's storage (fp32 activations: 4 B per element
+                # of SURVEY 8d's (Cin+Cout)*HW); the same elements at the survey's bf16 convention (2 B) and the MFMA-side fraction
+                # are given next to it so that rounds stay comparable whatever the storage format
+                'frac_fp32_storage_bytes': round(gbs / PEAK_HBM_GBS, 4), 'frac_survey_bf16_bytes': round(gbs / 2 / PEAK_HBM_GBS, 4),
+                'frac_mfma_side': round(achieved / PEAK_BF16_TFLOPS, 4),
                 'launches': launches, 'avg_us': round(1e3 * ms / launches, 2),
                 'alg_gflop_per_launch': round(flops / launches / 1e9, 3),
                 'alg_mb_per_launch': round(byts / launches / 1e6, 3),
@@ -409,27 +430,58 @@ def main() -> None:
                 print(f'{ms / tot * 100:6.2f}%  {ms / n * 1e3:9.1f} us x {n:5d}  {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TF/s '
                       f'{by / (ms * 1e-3) / 1e9 if ms else 0:8.0f} GB/s  {name}', file=sys.stderr)
 
-        # ---- CPU baseline (rank 0, N=1): the oracle restatement on the host cores, bounded sample ----
+        # ---- CPU baseline (rank 0, N=1): the oracle restatement on the host cores, bounded sample; the same passes check eps
+        # over EVERY image of the timed batch (image 0 is pinned to t = 0, image 1 to t = 999) ----
         if world == 1 and not args.no_cpu_baseline:
+            import statistics
             from oracle import unet_ref as O
             ncores = host_cores()
             torch.set_num_threads(ncores)
             w = {k: v.detach().cpu() for k, v in dm.model.state_dict().items()}
             bufs = O.diffusion_buffers()
             nb = min(4, B)
-            xc, tc, nc = x0[:nb].cpu(), t[:nb].cpu(), noise[:nb].cpu()
+            xc, tc, nc = x0.cpu(), t.cpu(), noise.cpu()
+            eps_c = eps.cpu()
+            rates, num, den, worst = [], 0.0, 0.0, (0.0, -1)
             with torch.no_grad():
-                O.diffusion_forward(w, bufs, xc[:1], tc[:1], nc[:1])          # warm-up
-                c0 = time.perf_counter()
-                reps = 2
-                for _ in range(reps):
-                    ref = O.diffusion_forward(w, bufs, xc, tc, nc)
-                cpu_s = time.perf_counter() - c0
-            err = float((eps[:nb].cpu() - ref).norm() / ref.norm())
-            out['cpu_baseline'] = {'value': round(reps * nb / cpu_s, 3), 'unit': 'img/s', 'cores': torch.get_num_threads(),
-                                   'kind': 'port',
-                                   'sample': f'{reps} x {nb}x1x{S}x{S} fp32 q-sample+UNet forward (oracle/unet_ref.py, torch CPU ops), 1 warm-up'}
-            out['eps_rel_l2_vs_cpu'] = float(f'{err:.3e}')
+                O.diffusion_forward(w, bufs, xc[:nb], tc[:nb], nc[:nb])          # 1 warm-up pass at the timed shape
+                for b0 in range(0, B - nb + 1, nb):                               # B/nb timed passes (8 at B = 32): min & median
+                    c0 = time.perf_counter()
+                    ref = O.diffusion_forward(w, bufs, xc[b0:b0 + nb], tc[b0:b0 + nb], nc[b0:b0 + nb])
+                    rates.append(nb / (time.perf_counter() - c0))
+                    d = (eps_c[b0:b0 + nb].double() - ref.double())
+                    num += float(d.pow(2).sum())
+                    den += float(ref.double().pow(2).sum())
+                    for i in range(nb):
+                        e_i = float(d[i].norm() / ref[i].double().norm())
+                        if e_i > worst[0]:
+                            worst = (e_i, b0 + i)
+                # BASELINE configs[0] shape (8 x 1 x 64 x 64, the reference's CPU-runnable plumbing case): 1 warm-up + 3 timed
+                g1 = torch.Generator().manual_seed(4321)
+                x1, t1, n1 = torch.rand(8, 1, 64, 64, generator=g1), torch.randint(0, 1000, (8,), generator=g1), torch.randn(8, 1, 64, 64, generator=g1)
+                O.diffusion_forward(w, bufs, x1, t1, n1)
+                r1 = []
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    ref1 = O.diffusion_forward(w, bufs, x1, t1, n1)
+                    r1.append(8 / (time.perf_counter() - c0))
+                e1 = dm.model(dm._q_sample(x1.to(dev), t1.to(dev), n1.to(dev), normalize=True), t1.to(dev)).cpu()
+                err1 = float((e1.double() - ref1.double()).norm() / ref1.double().norm())
+            try:
+                cpu_model = next(ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name'))
+            except Exception:
+                cpu_model = 'unknown'
+            out['cpu_baseline'] = {'value': round(statistics.median(rates), 3), 'unit': 'img/s', 'cores': torch.get_num_threads(),
+                                   'kind': 'port', 'cpu_model': cpu_model,
+                                   'min': round(min(rates), 3), 'median': round(statistics.median(rates), 3), 'max': round(max(rates), 3),
+                                   'timed_passes': len(rates),
+                                   'sample': f'{len(rates)} timed passes of {nb}x1x{S}x{S} (all {len(rates) * nb} images of the GPU batch) after 1 '
+                                             f'warm-up pass, fp32 q-sample+UNet forward (oracle/unet_ref.py, torch CPU ops); value = median',
+                                   'config1_8x1x64x64': {'min': round(min(r1), 2), 'median': round(statistics.median(r1), 2), 'unit': 'img/s',
+                                                         'timed_passes': 3, 'gpu_eps_rel_l2': float(f'{err1:.3e}')}}
+            out['eps_rel_l2_vs_cpu'] = float(f'{(num / den) ** 0.5:.3e}')
+            out['eps_check'] = {'images': len(rates) * nb, 'worst_sample_rel_l2': float(f'{worst[0]:.3e}'), 'worst_sample_index': worst[1],
+                                'worst_sample_t': int(tc[worst[1]]), 't0_sample_included': bool((tc[:len(rates) * nb] == 0).any())}
             out['eps_gate'] = 1e-3
         print(json.dumps(out), flush=True)
 

@@ -7,10 +7,12 @@
 
 Data: chest-like images = smooth background + two brighter "lung" ellipses of random position/size + noise; target = the
 ellipse mask (what `dataloaders/JSRT.py` yields as (image, mask), both in [0,1]).  Model: `tedm_amd.DatasetDM` with a
-randomly initialised frozen `DiffusionModel` (no trained checkpoint ships with the reference) and the 8 TEDM timesteps
-(train.py:47); only `classifier` is trained: BCE-with-logits (train_baseline.py:44), Adam lr 1e-4 (config.py), prediction
-`sigmoid > 0.5`, Dice / precision / recall as train_baseline.py:146-161.  Under torch.distributed every rank trains on its
-shard, classifier gradients are averaged with one all-reduce per parameter (BatchNorm statistics stay per rank)."""
+randomly initialised frozen `DiffusionModel` (no trained checkpoint ships with the reference), the 8 TEDM timesteps
+(train.py:47) and the SHARED-WEIGHTS classifier (trainers/train_datasetDM.py:30-42); only `classifier` is trained, through
+`tedm_amd.tedm.train_head` (= trainers/train_baseline.py:17-96: replicated targets, BCE-with-logits, Adam lr 1e-4 (config.py));
+prediction = mean over the timesteps of the sigmoids > 0.5 (app.py:79), Dice / precision / recall as train_baseline.py:146-161.
+Under torch.distributed every rank trains on its shard, the head's gradients cross ranks in ONE flat all-reduce (BatchNorm
+statistics stay per rank)."""
 import argparse
 import os
 import sys
@@ -38,59 +40,47 @@ def make_data(n, S, seed):
     return torch.stack(xs), torch.stack(ys)
 
 
-def dice_pr(y_hat, y):
-    inter = (y_hat & y).flatten(1).sum(1).float()
-    d = 2 * inter / (y_hat.flatten(1).sum(1) + y.flatten(1).sum(1)).float()
-    return d.nanmean().item(), (inter / y_hat.flatten(1).sum(1).float()).nanmean().item(), (inter / y.flatten(1).sum(1).float()).nanmean().item()
-
-
-def run(steps=60, size=128, n_train=32, n_val=8, batch=8, lr=1e-4, seed=0, verbose=True):
-    from tedm_amd import DatasetDM, dp
+def run(steps=60, size=128, n_train=32, n_val=8, batch=8, lr=1e-4, seed=0, verbose=True, shared=True):
+    """Returns the list of validation dicts (tedm.validate_head: val/loss, val/dice, val/precision, val/recall, val/dice_ensemble),
+    first entry = before training."""
+    from tedm_amd import DatasetDM, dp, tedm
     world, rank, local = dp.env_world()
     dist = dp.init(os.environ.get('TEDM_DIST_BACKEND', 'nccl')) if world > 1 else None
     dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     torch.manual_seed(seed)                                   # same head initialisation on every rank
-    model = DatasetDM(Namespace(normalize=True, dim=64, saved_diffusion_model='/nonexistent', verbose=False, device='cuda',
-                                t_steps_to_save=[1, 10, 25, 50, 200, 400, 600, 800])).to(dev)
-    model.diffusion_model.eval()
+    cfg = Namespace(normalize=True, dim=64, saved_diffusion_model='/nonexistent', verbose=False, device=str(dev),
+                    t_steps_to_save=[1, 10, 25, 50, 200, 400, 600, 800],          # train.py:47
+                    shared_weights_over_timesteps=shared, experiment='TEDM', lr=lr, weight_decay=0.0,
+                    log_freq=max(1, steps // 4), val_freq=max(1, steps // 4), max_steps=steps, max_val_steps=-1, debug=False,
+                    early_stop=False, log_dir=os.path.join(os.environ.get('TMPDIR', '/tmp'), f'tedm_synth_rank{rank}'))
+    model = DatasetDM(cfg).to(dev)
     for p in model.diffusion_model.parameters():
         p.requires_grad_(False)
-    opt = torch.optim.Adam(model.classifier.parameters(), lr=lr)
+    opt = torch.optim.Adam(model.classifier.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)   # train_datasetDM.py:46
     xtr, ytr = make_data(n_train, size, 100)
     xva, yva = make_data(n_val, size, 200)
     beg, end = dp.shard_range(n_train, world, rank)
-    xtr, ytr = xtr[beg:end].to(dev), ytr[beg:end].to(dev)
-    xva, yva = xva.to(dev), yva.to(dev)
-
-    def validate():
-        model.eval()
-        with torch.no_grad():
-            pred = torch.cat([model(xva[i:i + batch]) for i in range(0, n_val, batch)])
-        model.train()
-        model.diffusion_model.eval()
-        d, p, r = dice_pr(torch.sigmoid(pred) > 0.5, yva > 0.5)
-        return float(F.binary_cross_entropy_with_logits(pred, yva)), d, p, r
-
-    model.train()
-    model.diffusion_model.eval()
-    hist = [validate()]
+    xtr, ytr = xtr[beg:end], ytr[beg:end]
     g = torch.Generator().manual_seed(seed + rank)
-    for step in range(1, steps + 1):
-        idx = torch.randint(0, xtr.shape[0], (min(batch, xtr.shape[0]),), generator=g).to(dev)
-        opt.zero_grad()
-        loss = F.binary_cross_entropy_with_logits(model(xtr[idx]), ytr[idx])
-        loss.backward()
-        if dist is not None:
-            for p in model.classifier.parameters():
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                p.grad.div_(world)
-        opt.step()
-        if step % max(1, steps // 4) == 0 or step == steps:
-            hist.append(validate())
-            if verbose and rank == 0:
-                print(f'step {step:4d}  train loss {float(loss.detach()):.4f}  val loss {hist[-1][0]:.4f}  dice {hist[-1][1]:.3f}  '
-                      f'precision {hist[-1][2]:.3f}  recall {hist[-1][3]:.3f}', flush=True)
+
+    class Loader:                                             # a shuffling (x, y) loader, like dataloaders/JSRT.py's DataLoader
+        def __iter__(self):
+            perm = torch.randperm(xtr.shape[0], generator=g)
+            for i in range(0, len(perm) - batch + 1, batch) or [0]:
+                idx = perm[i:i + batch]
+                yield xtr[idx], ytr[idx]
+    val = [(xva[i:i + batch], yva[i:i + batch]) for i in range(0, n_val, batch)]
+    hist = [tedm.validate_head(cfg, model, val, dist)]
+
+    class Logger:
+        def log(self, d, step):
+            if 'val/loss' in d:
+                hist.append(d)
+                if verbose and rank == 0:
+                    print(f"step {step:4d}  val loss {d['val/loss']:.4f}  dice/step {d['val/dice']:.3f}  precision {d['val/precision']:.3f}  "
+                          f"recall {d['val/recall']:.3f}  dice(ensemble) {d['val/dice_ensemble']:.3f}", flush=True)
+    tedm.train_head(cfg, model, opt, Loader(), val, Logger(), dist=dist)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -105,6 +95,7 @@ if __name__ == '__main__':
     ap.add_argument('--val', type=int, default=8)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--ledme', action='store_true', help='the LEDMe head (one classifier on the 960*8-channel concat) instead of TEDM')
     a = ap.parse_args()
-    h = run(a.steps, a.size, a.train, a.val, a.batch, a.lr)
-    print(f'held-out Dice: {h[0][1]:.3f} -> {h[-1][1]:.3f}')
+    h = run(a.steps, a.size, a.train, a.val, a.batch, a.lr, shared=not a.ledme)
+    print(f"held-out Dice (mean-over-steps mask): {h[0]['val/dice_ensemble']:.3f} -> {h[-1]['val/dice_ensemble']:.3f}")

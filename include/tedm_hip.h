@@ -155,6 +155,14 @@ int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t
 long long tedm_unet_tape_generation(const tedm_unet* h);
 int tedm_unet_backward_gen(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream,
                            long long generation);
+/* Data-parallel training (not in the reference, which has no distributed code): `fn(user, group)` is called from
+ * inside tedm_unet_backward, on the calling thread, each time every gradient of one top-level module has been ENQUEUED on the
+ * stream -- group = its state-dict prefix, in the order final_conv, final_res_block, ups.{n-1..0}, mid_block2, mid_attn,
+ * mid_block1, downs.{n-1..0}, init_conv, time_mlp (the flat gradient buffer completes from its end towards its start).  The host
+ * records an event there and launches the all-reduce of the finished slice on a side stream, so that communication hides under
+ * the rest of the backward (tedm_amd/dp.py).  fn = NULL removes the hook.  The callback must not call back into the handle. */
+typedef void (*tedm_backward_mark_fn)(void* user, const char* group);
+int tedm_unet_set_backward_callback(tedm_unet* h, tedm_backward_mark_fn fn, void* user);
 /* DiffusionModel.train_step's loss (models/diffusion_model.py:138-143):
  *   loss = mean_b( mean_chw |eps - target| * p2w[t_b] ),  grad = d loss / d eps  (grad may be NULL).
  * scratch: B*64 floats; loss: 1 float; all device pointers. */

@@ -292,3 +292,60 @@ def pixel_classifier(pc: Params, feats: Tensor, training: bool = False) -> Tenso
     x = F.batch_norm(x, pc['5.running_mean'], pc['5.running_var'], pc['5.weight'], pc['5.bias'],
                      training=training, eps=1e-5)
     return F.conv2d(x, pc['6.weight'], pc['6.bias'])
+
+
+# --------------------------------------------------------------------------------------
+# TEDM: shared-weights classifier, ensembling, metrics
+#       reference: trainers/train_datasetDM.py, trainers/train_baseline.py, app.py,
+#                  auxiliary/postprocessing/testing_shared_weights.py
+# --------------------------------------------------------------------------------------
+def tedm_classifier(pc: Params, feats: Tensor, n_steps: int, training: bool = False) -> Tensor:
+    """trainers/train_datasetDM.py:30-42 -- Rearrange('b (step act) h w -> (b step) act h w') followed by the SAME
+    Conv1x1(960,128) -> ReLU -> BN -> Conv1x1(128,32) -> ReLU -> BN -> Conv1x1(32,1) for every timestep.
+    `pc` keys are the nn.Sequential indices behind the Rearrange: '1.*', '3.*', '4.*', '6.*', '7.*'.  Output
+    (B*n_steps, 1, S, S), row index b*n_steps + step.  With training=True BatchNorm uses the statistics of the
+    (B*n_steps) pixel batch (single-device semantics of the reference)."""
+    B, CT, H, W = feats.shape
+    x = feats.reshape(B, n_steps, CT // n_steps, H, W).reshape(B * n_steps, CT // n_steps, H, W)
+    shifted = {f'{int(k.split(".", 1)[0]) - 1}.{k.split(".", 1)[1]}': v for k, v in pc.items()}
+    return pixel_classifier(shifted, x, training=training)
+
+
+def tedm_ensemble(logits: Tensor, n_steps: int) -> Tuple[Tensor, Tensor]:
+    """auxiliary/postprocessing/testing_shared_weights.py:113-133 (and app.py:79 for one image): sigmoid, regroup
+    '(b step) 1 h w -> step b 1 h w', mean over the timesteps, threshold at 0.5.  Returns (probability, mask)."""
+    p = torch.sigmoid(logits)
+    p = p.reshape(-1, n_steps, *p.shape[1:]).transpose(0, 1).mean(0)
+    return p, p > .5
+
+
+def replicate_targets(y: Tensor, n_steps: int) -> Tensor:
+    """trainers/train_baseline.py:30 -- repeat(y, 'b c h w -> (b step) c h w')."""
+    return y.repeat_interleave(n_steps, dim=0)
+
+
+def bce_loss(pred: Tensor, y: Tensor) -> Tuple[Tensor, Tensor]:
+    """trainers/train_baseline.py:44-45 -- BCE-with-logits, mean over (h, w) per (b, c), then mean.  Returns
+    (loss, expanded_loss (b, c))."""
+    e = F.binary_cross_entropy_with_logits(pred, y, reduction='none').mean(dim=(2, 3))
+    return e.mean(), e
+
+
+def dice(x_hat: Tensor, x: Tensor) -> Tensor:
+    """trainers/train_baseline.py:146-149, per (b, c); 0/0 -> nan as in the reference."""
+    inter = torch.logical_and(x_hat, x).sum(dim=(2, 3))
+    return 2 * inter / (x_hat.sum(dim=(2, 3)) + x.sum(dim=(2, 3)))
+
+
+def precision(x_hat: Tensor, x: Tensor) -> Tensor:
+    """trainers/train_baseline.py:151-155."""
+    tp = torch.logical_and(x, x_hat).sum(dim=(2, 3))
+    fp = torch.logical_and(1 - x, x_hat).sum(dim=(2, 3))
+    return tp / (tp + fp)
+
+
+def recall(x_hat: Tensor, x: Tensor) -> Tensor:
+    """trainers/train_baseline.py:157-161."""
+    tp = torch.logical_and(x, x_hat).sum(dim=(2, 3))
+    fn = torch.logical_and(x, ~x_hat).sum(dim=(2, 3))
+    return tp / (tp + fn)

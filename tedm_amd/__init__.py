@@ -6,7 +6,8 @@ models/datasetDM_model.py `DatasetDM`).  Compute: hand-written HIP kernels for g
 tedm_amd/csrc behind the C ABI of include/tedm_hip.h (libtedm_hip.so, loaded with ctypes).
 
 Also here: `trainer` (the reference training loop / checkpoint format over the native train step), `dp` (one process per
-GPU: sharding, flat-gradient all-reduce), `head` (pixel-classifier first layer fused into the decoder taps).
+GPU: sharding, flat-gradient all-reduce), `head` (pixel-classifier first layer fused into the decoder taps), `tedm` (the
+shared-weights classifier over timesteps, its training loop, mean-over-steps ensembling, Dice / precision / recall).
 """
 from .unet import Unet                      # noqa: F401
 from .diffusion import DiffusionModel       # noqa: F401

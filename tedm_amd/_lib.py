@@ -24,6 +24,9 @@ class UnetCfg(C.Structure):
                 ('heads', C.c_int), ('dim_head', C.c_int)]
 
 
+BACKWARD_MARK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)      # tedm_hip.h: tedm_backward_mark_fn
+
+
 class TedmError(RuntimeError):
     pass
 
@@ -49,6 +52,7 @@ _SIGNATURES = {
     'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     'tedm_unet_backward_gen': (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_longlong]),
     'tedm_unet_tape_generation': (C.c_longlong, [_P]),
+    'tedm_unet_set_backward_callback': (C.c_int, [_P, _P, _P]),
     'tedm_l1_loss': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, _P, _P, _P, _P]),
     'tedm_unet_module_channels': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tedm_unet_module_workspace_bytes': (C.c_size_t, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int]),

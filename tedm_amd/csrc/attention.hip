@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const float* __restrict_
     const int qtiles = (ntok + 31) / 32;
     const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gid >= (long long)B * qtiles * heads) return;
+    // fp16 conversions saturate at +-65504 for the rest of the kernel: an un-normalised V beyond fp16's range degrades to the
+    // clamped hi + clamped lo instead of hi = inf, lo = v - inf = NaN (q, k are l2-normalised, P is in [0, 1]).  ADVICE r2.
+    fp16_saturate_on();
     const int head = (int)(gid % heads);
     const int qt = (int)((gid / heads) % qtiles);
     const int b = (int)(gid / ((long long)heads * qtiles));

@@ -194,7 +194,21 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
     const int KS4 = Cin * 4;                                // k-steps
     float* sx = (float*)smem;                               // [Cin][HR + 1][HC]  (one extra zero row: tap row 7)
     uint4* swf = (uint4*)(sx + ((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3));     // [k-step][cout tile][hi|lo][64 lanes] B fragments
+    float* swe = (float*)(swf + (size_t)KS4 * NCB * 2 * 64);                    // [2][Cout]: 2^-e, 2^e of each output channel's weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Conversions saturate at +-65504 instead of producing inf (hi = inf would make lo = v - inf = NaN), and every output
+    // channel's weights are pre-scaled by a power of two into [1, 2) so that small weights do not fall into fp16's subnormal
+    // range and lose the lo term (both exact: the scale is undone on the fp32 accumulator).  ADVICE r2.
+    fp16_saturate_on();
+    if (tid < Cout) {
+        float amax = 0.f;
+        for (int i = 0; i < Cin * 49; ++i) amax = fmaxf(amax, fabsf(w[(size_t)tid * Cin * 49 + i]));
+        int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;
+        e = amax > 0.f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
+        swe[tid] = ldexpf(1.f, -e);
+        swe[Cout + tid] = ldexpf(1.f, e);
+    }
+    __syncthreads();
     const int li = lane & 31, lk = lane >> 5;
     const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
     int tile = blockIdx.x;
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
         const int ci = ks >> 2, s_ = ks & 3, co = c * 32 + (ln & 31), ky = 2 * s_ + (ln >> 5);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (j < 7 && ky < 7 && co < Cout) ? w[((size_t)co * Cin + ci) * 49 + ky * 7 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (j < 7 && ky < 7 && co < Cout) ? w[((size_t)co * Cin + ci) * 49 + ky * 7 + j] * swe[co] : 0.f;
         f16x8 hi, lo;
         stem_split(v, hi, lo);
         swf[((ks * NCB + c) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
@@ -269,11 +283,11 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             const int co = c * 32 + li;
-            const float bs = bias[co];
+            const float bs = bias[co], sc = swe[Cout + co];
 #pragma unroll
             for (int s_ = 0; s_ < 16; ++s_) {
                 const int ox = ox0 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk;
-                if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = acc[m][c][s_] + bs;
+                if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = fmaf(acc[m][c][s_], sc, bs);
             }
         }
     }
@@ -678,7 +692,7 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
     const int tiles = ((W + STEM_TC - 1) / STEM_TC) * ((H + STEM_TR - 1) / STEM_TR);
     const int K = Cin * 49;
     if (Cin <= 2 && (Cout == 32 || Cout == 64)) {                 // fp16 hi/lo matrix-core path (the model's stem: Cin = 1)
-        const size_t lds = (size_t)((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 4 * (Cout / 32) * 2 * 1024;
+        const size_t lds = (size_t)((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 4 * (Cout / 32) * 2 * 1024 + (size_t)2 * Cout * 4;
         if (Cout == 32) hipLaunchKernelGGL(stem_conv_f16_kernel<1>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
         else hipLaunchKernelGGL(stem_conv_f16_kernel<2>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
         return LAUNCH_OK();

@@ -209,6 +209,8 @@ struct tedm_unet {
     bool packed_bwd = false;
     Tape tape;
     long long tape_gen = 0; // bumped by every tedm_unet_forward_train
+    tedm_backward_mark_fn bwd_cb = nullptr;   // tedm_unet_set_backward_callback: bucketed gradient all-reduce hooks in here
+    void* bwd_cb_user = nullptr;
 
     ~tedm_unet() {
         for (ConvW* c : convs) {
@@ -847,6 +849,13 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
 }
 
 long long tedm_unet_tape_generation(const tedm_unet* h) { return h ? h->tape_gen : 0; }
+
+int tedm_unet_set_backward_callback(tedm_unet* h, tedm_backward_mark_fn fn, void* user) {
+    g_err[0] = 0;
+    if (!h) return fail(TEDM_EINVAL, "null handle");
+    h->bwd_cb = fn; h->bwd_cb_user = user;
+    return TEDM_OK;
+}
 
 int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream) {
     return tedm_unet_backward_gen(h, d_eps, workspace, workspace_bytes, stream, 0);

@@ -41,9 +41,17 @@ class DatasetDM(nn.Module):
         feat_ch = sum(s[3] for s in self.diffusion_model.model._tap_shapes(1, 8, 8))   # 960 for the default UNet
         self.feature_channels = feat_ch
         self.fused_head = bool(getattr(args, 'fused_head', True))
-        self.classifier = nn.Sequential(                                       # datasetDM_model.py:57-64
-            nn.Conv2d(feat_ch * len(self.steps), 128, 1), nn.ReLU(), nn.BatchNorm2d(128),
-            nn.Conv2d(128, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
+        # TEDM (trainers/train_datasetDM.py:30-42): ONE classifier shared by all timesteps.  The reference swaps it in after
+        # construction; both routes work here (`args.shared_weights_over_timesteps`, config.py, or assigning
+        # `model.classifier = nn.Sequential(Rearrange(...), nn.Conv2d(960, 128, 1), ...)` later).
+        self.shared_weights_over_timesteps = bool(getattr(args, 'shared_weights_over_timesteps', False))
+        if self.shared_weights_over_timesteps:
+            from .tedm import shared_weights_classifier
+            self.classifier = shared_weights_classifier(len(self.steps), feat_ch, int(getattr(args, 'out_channels', 1)))
+        else:
+            self.classifier = nn.Sequential(                                   # datasetDM_model.py:57-64
+                nn.Conv2d(feat_ch * len(self.steps), 128, 1), nn.ReLU(), nn.BatchNorm2d(128),
+                nn.Conv2d(128, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
 
     @torch.no_grad()
     def extract_features(self, x_0: Tensor, noise: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
@@ -105,18 +113,64 @@ class DatasetDM(nn.Module):
                 out.append([tp[j * B:(j + 1) * B] for tp in taps])
         return out
 
+    @torch.no_grad()
+    def _taps_steps_in_batch(self, x_0: Tensor, noise: Optional[Tensor] = None):
+        """The decoder taps of the B*T noised images in '(b step)' order (row b*T + step: the order the shared-weights
+        classifier's Rearrange produces, trainers/train_datasetDM.py:34) as 4 NCHW-shaped views of NHWC buffers
+        (B*T, C_i, h_i, w_i).  The UNet has no cross-sample op, so stacking the timesteps into the batch is exact; the
+        native forwards are cut at `max_images_per_forward` images along b."""
+        dm, unet = self.diffusion_model, self.diffusion_model.model
+        B, T, dev = x_0.shape[0], len(self.steps), x_0.device
+        steps = torch.tensor([int(s) for s in self.steps], dtype=torch.long, device=dev)
+        nb = max(1, self.max_images_per_forward // T)
+        chunks = []
+        for b0 in range(0, B, nb):
+            xb = x_0[b0:b0 + nb]
+            n = xb.shape[0]
+            xr = xb.repeat_interleave(T, dim=0)
+            t = steps.repeat(n)
+            nz = noise[b0:b0 + nb].repeat_interleave(T, dim=0) if noise is not None else None   # one noise per image (:68-76)
+            x_t, _ = dm.forward_diffusion_model(x_0=xr, t=t, noise=nz)                           # un-normalised x_0 (:76)
+            _, taps = unet.native_forward(x_t, t, taps_only=True)
+            chunks.append(taps)
+        if len(chunks) == 1:
+            return chunks[0]
+        return [torch.cat([c[i].permute(0, 2, 3, 1) for c in chunks], 0).permute(0, 3, 1, 2) for i in range(len(chunks[0]))]
+
+    def head_layout(self):
+        """('concat', i) : classifier[i] is the reference's Conv2d(960*T, ., 1) on the channel concat (datasetDM_model.py:57-64);
+        ('shared', i)   : classifier[0] regroups '(step act) -> (b step)' and classifier[i] is Conv2d(960, ., 1) (TEDM);
+        None            : anything else -> the unfused path `classifier(extract_features(x))`."""
+        from .tedm import is_steps_to_batch
+        c = self.classifier
+        if not isinstance(c, nn.Sequential) or len(c) == 0:
+            return None
+
+        def ok(conv, cin):
+            return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+                    and conv.out_channels % 16 == 0 and conv.in_channels == cin)
+        if is_steps_to_batch(c[0]):
+            n = getattr(c[0], 'n_steps', None) or dict(getattr(c[0], 'axes_lengths', ())).get('step')
+            if n == len(self.steps) and len(c) > 1 and ok(c[1], self.feature_channels):
+                return ('shared', 1)
+            return None
+        if ok(c[0], self.feature_channels * len(self.steps)):
+            return ('concat', 0)
+        return None
+
     def forward(self, x: Tensor, noise: Optional[Tensor] = None) -> Tensor:
         """datasetDM_model.py:85-88.  With `fused_head` (default) the first classifier layer runs at the taps' native
         resolution (tedm_amd/head.py) and the (B, 960*T, S, S) feature tensor is never built; the result equals
-        `classifier(extract_features(x))` up to fp32 summation order.  `noise` pins the q-sample noise (tests)."""
-        conv = self.classifier[0]
-        fused = (self.fused_head and isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.out_channels % 16 == 0
-                 and conv.in_channels == self.feature_channels * len(self.steps))
-        if not fused:
+        `classifier(extract_features(x))` up to fp32 summation order.  `noise` pins the q-sample noise (tests).
+        Shared-weights (TEDM) head: output (B*T, 1, S, S) in '(b step)' order; the 960 -> 128 projection runs ONCE per tap
+        over the B*T images with the same weights (no accumulation over t)."""
+        layout = self.head_layout() if self.fused_head else None
+        if layout is None:
             return self.classifier(self.extract_features(x, noise=noise).to(x.device))
         from .head import fused_first_layer
-        taps = self._taps_per_step(x, noise)
+        kind, ci = layout
         unet = self.diffusion_model.model                       # the head trains at the UNet's training precision
         prec = unet.train_precision if (torch.is_grad_enabled() and self.training) else unet.precision
-        h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
-        return self.classifier[1:](h1)
+        taps = [self._taps_steps_in_batch(x, noise)] if kind == 'shared' else self._taps_per_step(x, noise)
+        h1 = fused_first_layer(self.classifier[ci], taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
+        return self.classifier[ci + 1:](h1)

@@ -45,7 +45,8 @@ class DiffusionModel(nn.Module):
         self.timesteps = int(get('timesteps', 1000))
         self.objective = get('objective', 'pred_noise')
         self.dynamic_threshold_percentile = get('dynamic_threshold_percentile', 0.995)
-        self.model = Unet(get('dim', 64), dim_mults=get('dim_mults', [1, 2, 4, 8]), channels=get('channels', 1))
+        self.model = Unet(get('dim', 64), dim_mults=get('dim_mults', [1, 2, 4, 8]), channels=get('channels', 1),
+                          precision=get('precision', None), train_precision=get('train_precision', None))   # build-only keys
 
         betas = make_betas(get('beta_schedule', 'cosine'), self.timesteps)
         alphas = 1. - betas
@@ -128,7 +129,7 @@ class DiffusionModel(nn.Module):
         return loss, grad
 
     def train_step_native(self, x_0: Tensor, cond: Optional[Tensor] = None, t: Optional[Tensor] = None,
-                          noise: Optional[Tensor] = None) -> Tensor:
+                          noise: Optional[Tensor] = None, on_backward_group=None) -> Tensor:
         """`train_step` + `loss.backward()` (trainers/train_base_diffusion.py:36-47) without autograd:
         q-sample, recorded UNet forward, L1/p2 loss and the whole backward as HIP kernels.  Every
         `param.grad` of the UNet is (re)pointed at its view of `model.grad_flat` and OVERWRITTEN, which is
@@ -147,7 +148,7 @@ class DiffusionModel(nn.Module):
         x_t = self._q_sample(x_0, t, noise, normalize=bool(self.config.normalize))
         eps = self.model.native_forward_train(x_t, t)
         loss, grad = self.l1_loss_native(eps, target, t, want_grad=True)
-        views = self.model.native_backward(grad)
+        views = self.model.native_backward(grad, on_group=on_backward_group)    # on_group: bucketed all-reduce hook (tedm_amd/dp.py)
         for k, p in self.model.named_parameters():
             p.grad = views[k]
         return loss

@@ -92,13 +92,127 @@ def allreduce_grads_(dist, flat: torch.Tensor, local_n: int, global_n: int) -> t
     Each rank's `flat` holds d(mean over its local_n samples)/d(params).  The global mean over
     global_n = sum(local_n) samples is sum_r (local_n_r / global_n) * local_mean_r, so the buffer is scaled by
     local_n / global_n and summed over ranks: ONE all-reduce of the whole flat gradient buffer (RCCL ring
-    over xGMI on GPUs, gloo on CPU) -- no per-tensor buckets, the backward writes straight into `flat`."""
+    over xGMI on GPUs, gloo on CPU), the backward writes straight into `flat`.  `BucketedGradReducer` below does the same
+    in ~4 slices launched while the backward is still running."""
     if dist is None:
         return flat
     if local_n != global_n:
         flat.mul_(local_n / float(global_n))
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+# Backward completion order of the top-level modules (include/tedm_hip.h: tedm_unet_set_backward_callback); the flat gradient
+# buffer is laid out in PARAMETER order, so it completes from its end towards its start (init_conv / time_mlp last).
+def backward_group_order(n_levels: int = 4):
+    return (['final_conv', 'final_res_block'] + [f'ups.{i}' for i in reversed(range(n_levels))] +
+            ['mid_block2', 'mid_attn', 'mid_block1'] + [f'downs.{i}' for i in reversed(range(n_levels))] + ['init_conv', 'time_mlp'])
+
+
+def top_group(key: str) -> str:
+    """Top-level module of a state-dict key: 'ups.1.0.block1.proj.weight' -> 'ups.1', 'mid_attn.fn...' -> 'mid_attn'."""
+    parts = key.split('.')
+    return '.'.join(parts[:2]) if parts[0] in ('ups', 'downs') else parts[0]
+
+
+def grad_layout(named_sizes, n_levels: int = 4):
+    """Order of the parameters inside the flat gradient buffer: the REVERSE of the backward's completion order of their
+    top-level modules (time_mlp, init_conv, downs.0.., mid_block1, mid_attn, mid_block2, ups.0.., final_res_block, final_conv), so
+    that the buffer becomes final contiguously from its end towards its start while the backward runs.  Within a module the
+    `named_parameters()` order is kept.  `named_sizes`: iterable of (key, numel)."""
+    named_sizes = list(named_sizes)
+    rank = {g: i for i, g in enumerate(reversed(backward_group_order(n_levels)))}
+    unknown = sorted({top_group(k) for k, _ in named_sizes} - set(rank))
+    if unknown:
+        raise ValueError(f'parameters outside the known top-level modules: {unknown}')
+    return sorted(named_sizes, key=lambda kn: rank[top_group(kn[0])])          # stable: keeps the order inside a module
+
+
+def plan_buckets(layout, n_levels: int = 4, n_buckets: int = 4):
+    """Split the flat gradient buffer (parameters in `grad_layout` order) into ~n_buckets contiguous slices that become
+    complete, one after the other, while the backward is still running.
+
+    Returns [(last_group, lo, hi)] in completion order: when the backward reports `last_group` done, flat[lo:hi] is final.
+    Boundaries sit on top-level modules and balance BYTES (default model, 4 buckets: [final .. ups.1] 5.4 M, ups.0 14.6 M,
+    mid 10.2 M, downs + stem + time MLP 6.0 M elements).  The last bucket always closes with 'time_mlp' (written last)."""
+    order = backward_group_order(n_levels)
+    off, spans = 0, {}
+    for k, n in layout:
+        g = top_group(k)
+        lo, hi = spans.get(g, (off, off))
+        if hi != off:
+            raise ValueError(f'layout is not grouped by top-level module at {k}')
+        spans[g] = (lo, off + n)
+        off += n
+    total = off
+    if [g for g in order if g in spans] != list(reversed(list(spans))):
+        raise ValueError('layout is not the reverse of the backward completion order (use dp.grad_layout)')
+    target = total / float(max(1, n_buckets))
+    buckets, acc, hi = [], 0, total
+    present = [g for g in order if g in spans]
+    prev = None
+    for g in present[:-1]:
+        lo_g, hi_g = spans[g]
+        size = hi_g - lo_g
+        if prev is not None and acc > 0 and acc + size - target > target - acc and len(buckets) < n_buckets - 1:
+            buckets.append((prev, hi_g, hi))            # closing BEFORE g leaves the bucket nearer the target than taking g in
+            hi, acc = hi_g, 0
+        acc += size
+        if acc >= target and len(buckets) < n_buckets - 1:
+            buckets.append((g, lo_g, hi))
+            hi, acc = lo_g, 0
+        prev = g
+    buckets.append((present[-1], 0, hi))
+    assert buckets[0][2] == total and all(a[1] == b[2] for a, b in zip(buckets, buckets[1:]))
+    return buckets
+
+
+class BucketedGradReducer:
+    """sum-all-reduce the flat gradient buffer in ~4 buckets, each launched as soon as the backward has produced it
+    (decoder gradients first), so that RCCL traffic over xGMI hides under the remaining backward kernels.
+
+    `on_group(name)` is the backward's mark callback: at a bucket's last group it records an event on the compute stream and
+    enqueues, on a side stream that waits for that event, the scale by local_n/global_n and the all-reduce of the slice.
+    `finish()` makes the compute stream wait for all of them.  Bucketing does not change the result: every element is scaled
+    and summed over ranks exactly as by the single-buffer `allreduce_grads_` (bit-identical on 2 ranks, tests/test_dp_gloo.py).
+    Works on CPU tensors (gloo) for tests: no streams, the collectives run inline."""
+
+    def __init__(self, dist, flat: torch.Tensor, buckets, local_n: int, global_n: int):
+        self.dist, self.flat, self.buckets = dist, flat, list(buckets)
+        self.scale = None if local_n == global_n else local_n / float(global_n)
+        self.by_group = {g: (lo, hi) for g, lo, hi in self.buckets}
+        self.cuda = flat.is_cuda
+        self.side = torch.cuda.Stream(flat.device) if self.cuda else None
+        self.pending, self.done = [], []
+
+    def on_group(self, name: str) -> None:
+        span = self.by_group.get(name)
+        if span is None or self.dist is None:
+            return
+        lo, hi = span
+        sl = self.flat[lo:hi]
+        self.done.append(name)
+        if not self.cuda:
+            if self.scale is not None:
+                sl.mul_(self.scale)
+            self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            if self.scale is not None:
+                sl.mul_(self.scale)
+            self.pending.append(self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        if len(self.done) != len(self.buckets) and self.dist is not None:
+            raise RuntimeError(f'bucketed all-reduce: backward reported {self.done}, expected the groups {[b[0] for b in self.buckets]}')
+        for w in self.pending:
+            w.wait()                                         # the current stream waits for the collective
+        if self.cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        self.pending = []
 
 
 class DataParallelTrainer:
@@ -108,16 +222,26 @@ class DataParallelTrainer:
     forward+backward on its shard, all-reduces `dm.model.grad_flat` once and applies the same optimizer
     update (so replicas stay bit-identical when the collective is deterministic)."""
 
-    def __init__(self, dm, optimizer, dist=None):
-        self.dm, self.opt, self.dist = dm, optimizer, dist
+    def __init__(self, dm, optimizer, dist=None, n_buckets: int = 4):
+        self.dm, self.opt, self.dist, self.n_buckets = dm, optimizer, dist, n_buckets
+        self._buckets = None
 
     def step(self, x_local: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
              global_batch: Optional[int] = None) -> torch.Tensor:
         n = x_local.shape[0]
         world = self.dist.get_world_size() if self.dist is not None else 1
         gb = global_batch if global_batch is not None else n * world
-        loss = self.dm.train_step_native(x_local, t=t, noise=noise)
-        allreduce_grads_(self.dist, self.dm.model.grad_flat, n, gb)
+        unet = self.dm.model
+        if self.dist is None or self.n_buckets <= 1:
+            loss = self.dm.train_step_native(x_local, t=t, noise=noise)
+            allreduce_grads_(self.dist, unet.grad_flat, n, gb)
+        else:                                           # buckets go out while the backward is still running
+            if self._buckets is None:
+                self._buckets = plan_buckets(unet.grad_layout(), len(unet._cfg['dim_mults']), self.n_buckets)
+            unet.grad_views(x_local.device)              # allocates grad_flat on first use
+            red = BucketedGradReducer(self.dist, unet.grad_flat, self._buckets, n, gb)
+            loss = self.dm.train_step_native(x_local, t=t, noise=noise, on_backward_group=red.on_group)
+            red.finish()
         self.opt.step()
         if self.dist is not None:                      # report the global-batch loss like a DDP trainer's log line
             loss = loss * (n / float(gb))

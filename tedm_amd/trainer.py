@@ -10,8 +10,8 @@ Differences, all deliberate (SURVEY "do not reproduce" list):
   storage / bf16x3 products, there is no loss scaling;
 * validation returns the loss only (the reference also samples pictures for TensorBoard through
   `sample_plot_image(..., normalized=...)`, which raises TypeError as shipped);
-* under `torch.distributed` the image batch each rank receives is ITS shard; gradients are combined by one
-  all-reduce of the flat gradient buffer (tedm_amd.dp), only rank 0 writes checkpoints.
+* under `torch.distributed` the image batch each rank receives is ITS shard; gradients are combined by a bucketed
+  all-reduce of the flat gradient buffer launched while the backward runs (tedm_amd.dp), only rank 0 writes checkpoints.
 
 With a `tedm_amd.DiffusionModel` the step runs without autograd (`train_step_native`: q-sample, recorded UNet
 forward, L1/p2 loss, backward as HIP kernels).  Any other module exposing `train_step(x)` takes the generic
@@ -84,15 +84,14 @@ def train(config: Namespace, model, optimizer, train_loader: Iterable, val_loade
     world = dist.get_world_size() if dist is not None else 1
     native = hasattr(model, 'train_step_native') and 'cuda' in str(config.device)
     best_val, train_losses = float('inf'), []
+    dpt = dp.DataParallelTrainer(model, optimizer, dist, n_buckets=int(getattr(config, 'grad_buckets', 4))) if native else None
     model.train()
     while True:
         for batch in train_loader:
             step += 1
             x = _images(batch).to(config.device)
-            n = x.shape[0]
-            if native:                                              # HIP forward + loss + backward, grads in model.model.grad_flat
-                loss = model.train_step_native(x)
-                dp.allreduce_grads_(dist, model.model.grad_flat, n, n * world)
+            if native:      # HIP forward + loss + backward into model.model.grad_flat, bucketed all-reduce under the backward, Adam
+                lv = float(dpt.step(x).detach())                    # already the global-batch loss
             else:
                 optimizer.zero_grad()
                 loss = model.train_step(x)
@@ -102,10 +101,10 @@ def train(config: Namespace, model, optimizer, train_loader: Iterable, val_loade
                         if p.grad is not None:
                             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                             p.grad.div_(world)
-            optimizer.step()
-            lv = float(loss.detach())
-            if dist is not None:
-                lv = dp.sum_over_ranks(dist, lv, x.device if x.is_cuda else None) / world
+                optimizer.step()
+                lv = float(loss.detach())
+                if dist is not None:
+                    lv = dp.sum_over_ranks(dist, lv, x.device if x.is_cuda else None) / world
             train_losses.append(lv)
             if on_step is not None:
                 on_step(step, lv)

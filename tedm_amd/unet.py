@@ -158,6 +158,18 @@ def Downsample(dim: int, dim_out: Optional[int] = None) -> nn.Conv2d:
     return nn.Conv2d(dim, dim_out or dim, 4, 2, 1)
 
 
+class _Native:
+    """One native handle of a Unet facade and what the facade knows about its state."""
+    __slots__ = ('handle', 'device', 'fingerprint', 'bwd_fingerprint', 'bound')
+
+    def __init__(self):
+        self.handle = None
+        self.device = None
+        self.fingerprint = None          # (data_ptr, _version, dtype) of every bound tensor + precision the packs were made from
+        self.bwd_fingerprint = None      # fingerprint the data-gradient packs were derived from
+        self.bound: List[Tensor] = []    # keeps converted parameter copies alive
+
+
 class _UnetTrainFn(torch.autograd.Function):
     """autograd bridge: forward = tedm_unet_forward_train, backward = tedm_unet_backward.  Gradients are
     returned as copies of the `grad_flat` views so that autograd's accumulation semantics hold."""
@@ -224,22 +236,25 @@ class Unet(nn.Module):
         # ---- native side -----------------------------------------------------------------
         self._cfg = dict(dim=dim, init_dim=init_dim, out_dim=self.out_dim, dim_mults=dim_mults, channels=channels,
                          groups=resnet_block_groups, heads=4, dim_head=32)
-        self._handle = None
-        self._handle_device = None
-        self._fingerprint = None
-        self._bound: List[Tensor] = []          # keeps converted parameter copies alive
+        # Two native handles, one per ROLE: 'infer' (forward / module_forward, packed for `precision`) and 'train'
+        # (forward_train / backward, packed for `train_precision`, owns the tape and the data-gradient packs).  Each owns its
+        # packed weights, so an eval / sampling / validation forward between a training forward and its backward can neither
+        # re-encode the packs the outstanding tape needs nor clear the backward packs.
+        self._native: Dict[str, _Native] = {'infer': _Native(), 'train': _Native()}
         self._workspace: Optional[Tensor] = None
         self._train_ws: Optional[Tensor] = None
-        self._bwd_fingerprint = None
         self.grad_flat: Optional[Tensor] = None     # one flat fp32 buffer holding every parameter gradient
         self._grad_views: Dict[str, Tensor] = {}
         self._grad_handle = None
-        # Arithmetic mode of the MFMA contractions (tedm_hip.h TEDM_PREC_*).  Inference default 'f16f4' (fp16 MFMA + one
-        # block-scaled fp4 MFMA for the cross terms: eps 2e-4 from the fp32 reference, gate 1e-3); training forwards /
-        # backwards default to 'bf16x3' (gradients within 1e-4 per tensor of fp32 autograd).  TEDM_PREC / TEDM_TRAIN_PREC
-        # override; switching modes repacks the weights once.
-        self.precision = os.environ.get('TEDM_PREC', 'f16f4')
-        self.train_precision = os.environ.get('TEDM_TRAIN_PREC', os.environ.get('TEDM_PREC', 'bf16x3'))
+        # Arithmetic mode of the MFMA contractions (tedm_hip.h TEDM_PREC_*).  Module default 'bf16x3' for inference AND training
+        # (eps 2e-5 from the fp32 reference; gradients within 1e-4 per tensor of fp32 autograd).  The fast inference mode
+        # 'f16f4' (fp16 MFMA + one block-scaled fp4 MFMA for the cross terms, a single fp16 product inside the ResnetBlocks below
+        # full resolution: eps 2-4.5e-4, gate 1e-3, 1.7x faster) is an explicit opt-in -- `Unet(..., precision='f16f4')`,
+        # `config.precision`, `model.precision = 'f16f4'` or TEDM_PREC -- which bench.py takes and gates on its own eps check
+        # (its margin is measured on synthetic weights only).  Inference and training use separate native handles,
+        # so differing modes do not repack each other's weights.
+        self.precision = os.environ.get('TEDM_PREC') or kwargs.get('precision') or 'bf16x3'
+        self.train_precision = os.environ.get('TEDM_TRAIN_PREC') or kwargs.get('train_precision') or os.environ.get('TEDM_PREC') or 'bf16x3'
         self._module_ws: Optional[Tensor] = None
         for name, mod in self.named_modules():                  # back-reference for stand-alone calls (not a registered sub-module)
             if isinstance(mod, (ResnetBlock, Residual)):
@@ -255,24 +270,33 @@ class Unet(nn.Module):
         `p.data.clamp_()`, EMA `p.data.lerp_()`, `set_()`, external kernels writing through the pointer -- do NOT bump
         `_version`: call this after them, or the forward mixes stale packed conv weights with the live biases / norm
         parameters it reads through the bound pointers."""
-        self._fingerprint = None
-        self._bwd_fingerprint = None
+        for n in self._native.values():
+            n.fingerprint = None
+            n.bwd_fingerprint = None
 
     # -- native handle ---------------------------------------------------------------------
     def __del__(self):
         try:
-            if getattr(self, '_handle', None):
-                _lib.lib().tedm_unet_destroy(self._handle)
+            for n in getattr(self, '_native', {}).values():
+                if n.handle:
+                    _lib.lib().tedm_unet_destroy(n.handle)
+                    n.handle = None
         except Exception:
             pass
 
-    def _ensure_handle(self, device: torch.device):
+    @property
+    def _handle(self):
+        """The inference-role handle (trace / module queries)."""
+        return self._native['infer'].handle
+
+    def _ensure_handle(self, device: torch.device, role: str = 'infer') -> '_Native':
         L = _lib.lib()
-        if self._handle is not None and self._handle_device == device:
-            return
-        if self._handle is not None:
-            L.tedm_unet_destroy(self._handle)
-            self._handle = None
+        n = self._native[role]
+        if n.handle is not None and n.device == device:
+            return n
+        if n.handle is not None:
+            L.tedm_unet_destroy(n.handle)
+            n.handle = None
         c = self._cfg
         cfg = _lib.UnetCfg()
         cfg.dim, cfg.init_dim, cfg.out_dim = c['dim'], c['init_dim'], c['out_dim']
@@ -283,7 +307,8 @@ class Unet(nn.Module):
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(L.tedm_unet_create(C.byref(cfg), C.byref(h)), 'tedm_unet_create')
-        self._handle, self._handle_device, self._fingerprint = h, device, None
+        n.handle, n.device, n.fingerprint, n.bwd_fingerprint, n.bound = h, device, None, None, []
+        return n
 
     def _native_tensors(self) -> Dict[str, Tensor]:
         sd = {k: v for k, v in self.named_parameters()}
@@ -296,18 +321,21 @@ class Unet(nn.Module):
             raise ValueError(f'unknown precision {name!r} (use one of {sorted(_lib.PREC_BY_NAME)})')
         return name
 
-    def _sync_params(self, device: torch.device, stream_ptr: int, training: bool = False):
-        """(Re)bind parameter pointers and repack when anything changed (load_state_dict,
-        optimizer step, .to(), arithmetic mode)."""
+    def _sync_params(self, device: torch.device, stream_ptr: int, training: bool = False) -> '_Native':
+        """(Re)bind parameter pointers of the role's handle and repack when anything changed (load_state_dict,
+        optimizer step, .to(), arithmetic mode).  Returns the role's native state."""
         L = _lib.lib()
+        nat = self._ensure_handle(device, 'train' if training else 'infer')
         tensors = self._native_tensors()
         prec = self._prec_name(training)
         fp = tuple((t.data_ptr(), t._version, t.dtype) for t in tensors.values()) + (prec,)
-        if fp == self._fingerprint:
-            return
-        self._bound = []
-        n = L.tedm_unet_num_params(self._handle)
-        want = {L.tedm_unet_param_key(self._handle, i).decode() for i in range(n)}
+        if fp == nat.fingerprint:
+            return nat
+        nat.bound = []
+        nat.bwd_fingerprint = None              # the pack below re-encodes what the data-gradient packs were derived from
+        handle = nat.handle
+        n = L.tedm_unet_num_params(handle)
+        want = {L.tedm_unet_param_key(handle, i).decode() for i in range(n)}
         if want != set(tensors):
             raise _lib.TedmError(f'parameter set mismatch between facade and native plan: '
                                  f'{sorted(want ^ set(tensors))[:8]}')
@@ -317,11 +345,12 @@ class Unet(nn.Module):
             tt = t.detach()
             if tt.dtype != torch.float32 or not tt.is_contiguous():
                 tt = tt.float().contiguous()
-            self._bound.append(tt)
-            _lib.check(L.tedm_unet_set_param(self._handle, k.encode(), tt.data_ptr(), tt.numel()), f'set_param({k})')
-        _lib.check(L.tedm_unet_set_precision(self._handle, _lib.PREC_BY_NAME[prec]), 'set_precision')
-        _lib.check(L.tedm_unet_pack(self._handle, stream_ptr), 'tedm_unet_pack')
-        self._fingerprint = fp
+            nat.bound.append(tt)
+            _lib.check(L.tedm_unet_set_param(handle, k.encode(), tt.data_ptr(), tt.numel()), f'set_param({k})')
+        _lib.check(L.tedm_unet_set_precision(handle, _lib.PREC_BY_NAME[prec]), 'set_precision')
+        _lib.check(L.tedm_unet_pack(handle, stream_ptr), 'tedm_unet_pack')
+        nat.fingerprint = fp
+        return nat
 
     def _flags(self, taps_only: bool, trace: bool, training: bool = False) -> int:
         f = _lib.PREC_BY_NAME[self._prec_name(training)] << _lib.FWD_PREC_SHIFT
@@ -359,8 +388,7 @@ class Unet(nn.Module):
         B, _, H, W = x.shape
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            self._ensure_handle(dev)
-            self._sync_params(dev, stream)
+            handle = self._sync_params(dev, stream).handle
             xin = x.detach().float().contiguous()
             tin = None
             if timestep is not None:
@@ -368,7 +396,7 @@ class Unet(nn.Module):
                 if tin.numel() != B:
                     raise ValueError(f'timestep must have {B} elements, got {tin.numel()}')
             flags = self._flags(taps_only, trace)
-            need = L.tedm_unet_workspace_bytes(self._handle, B, H, W, flags)
+            need = L.tedm_unet_workspace_bytes(handle, B, H, W, flags)
             if need == 0:
                 _lib.check(-1, f'workspace sizing for input {tuple(x.shape)}')
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
@@ -381,7 +409,7 @@ class Unet(nn.Module):
                 taps = [torch.empty(s, dtype=torch.float32, device=dev) for s in self._tap_shapes(B, H, W)]
                 feat_ptrs = (C.c_void_p * len(taps))(*[t.data_ptr() for t in taps])
             _lib.check(L.tedm_unet_forward(
-                self._handle, xin.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
+                handle, xin.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
                 eps.data_ptr() if eps is not None else None, feat_ptrs, self._workspace.data_ptr(),
                 self._workspace.numel(), stream, flags), 'tedm_unet_forward')
             if trace:
@@ -402,7 +430,6 @@ class Unet(nn.Module):
         B, Cx, H, W = x.shape
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            self._ensure_handle(dev)
             self._sync_params(dev, stream)
             cin, cout = C.c_int(), C.c_int()
             _lib.check(L.tedm_unet_module_channels(self._handle, name.encode(), C.byref(cin), C.byref(cout)), f'module {name}')
@@ -429,21 +456,26 @@ class Unet(nn.Module):
     def grad_views(self, device: torch.device) -> Dict[str, Tensor]:
         """Per-parameter views into `grad_flat` (allocated and bound to the native handle on first use)."""
         L = _lib.lib()
-        self._ensure_handle(device)
+        handle = self._ensure_handle(device, 'train').handle
         params = dict(self.named_parameters())
         if self.grad_flat is None or self.grad_flat.device != device:
             total = sum(p.numel() for p in params.values())
             self.grad_flat = torch.zeros(total, dtype=torch.float32, device=device)
             self._grad_views, off = {}, 0
-            for k, p in params.items():
-                self._grad_views[k] = self.grad_flat[off:off + p.numel()].view(p.shape)
-                off += p.numel()
+            for k, n in self.grad_layout():          # reverse backward-completion order: the buffer finishes from its end (dp.py)
+                self._grad_views[k] = self.grad_flat[off:off + n].view(params[k].shape)
+                off += n
             self._grad_handle = None
-        if self._grad_handle is not self._handle:
+        if self._grad_handle is not handle:
             for k, v in self._grad_views.items():
-                _lib.check(L.tedm_unet_set_grad(self._handle, k.encode(), v.data_ptr(), v.numel()), f'set_grad({k})')
-            self._grad_handle = self._handle
+                _lib.check(L.tedm_unet_set_grad(handle, k.encode(), v.data_ptr(), v.numel()), f'set_grad({k})')
+            self._grad_handle = handle
         return self._grad_views
+
+    def grad_layout(self):
+        """[(key, numel)] in the order the parameters' gradients are laid out in `grad_flat` (dp.grad_layout)."""
+        from .dp import grad_layout
+        return grad_layout([(k, p.numel()) for k, p in self.named_parameters()], len(self._cfg['dim_mults']))
 
     def native_forward_train(self, x: Tensor, timestep: Optional[Tensor]) -> Tensor:
         """HIP forward that records the tape for `native_backward` in the training workspace."""
@@ -456,11 +488,11 @@ class Unet(nn.Module):
         B, _, H, W = x.shape
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            self._ensure_handle(dev)
-            self._sync_params(dev, stream, training=True)
-            if self._bwd_fingerprint != self._fingerprint:
-                _lib.check(L.tedm_unet_pack_backward(self._handle, stream), 'tedm_unet_pack_backward')
-                self._bwd_fingerprint = self._fingerprint
+            nat = self._sync_params(dev, stream, training=True)
+            handle = nat.handle
+            if nat.bwd_fingerprint != nat.fingerprint:
+                _lib.check(L.tedm_unet_pack_backward(handle, stream), 'tedm_unet_pack_backward')
+                nat.bwd_fingerprint = nat.fingerprint
             self.grad_views(dev)
             self._train_x = x.detach().float().contiguous()          # the stem's weight gradient reads it
             tin = None
@@ -468,7 +500,7 @@ class Unet(nn.Module):
                 tin = timestep.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
                 if tin.numel() != B:
                     raise ValueError(f'timestep must have {B} elements, got {tin.numel()}')
-            need = L.tedm_unet_train_workspace_bytes(self._handle, B, H, W)
+            need = L.tedm_unet_train_workspace_bytes(handle, B, H, W)
             if need == 0:
                 _lib.check(-1, f'training workspace sizing for input {tuple(x.shape)}')
             if self._train_ws is None or self._train_ws.numel() < need or self._train_ws.device != dev:
@@ -476,26 +508,45 @@ class Unet(nn.Module):
                 self._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
             eps = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=dev)
             _lib.check(L.tedm_unet_forward_train(
-                self._handle, self._train_x.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
+                handle, self._train_x.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
                 eps.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(), stream, self._flags(False, False, training=True)),
                 'tedm_unet_forward_train')
         return eps
 
     def tape_generation(self) -> int:
         """Generation of the training tape the native handle holds (bumped by every `native_forward_train`)."""
-        return int(_lib.lib().tedm_unet_tape_generation(self._handle)) if self._handle is not None else 0
+        h = self._native['train'].handle
+        return int(_lib.lib().tedm_unet_tape_generation(h)) if h is not None else 0
 
-    def native_backward(self, d_eps: Tensor, generation: int = 0) -> Dict[str, Tensor]:
+    def native_backward(self, d_eps: Tensor, generation: int = 0, on_group=None) -> Dict[str, Tensor]:
         """Backward of the last `native_forward_train`; overwrites `grad_flat` and returns its views.  `generation`
         (from `tape_generation()` right after the forward) makes the call fail loudly -- 'tape overwritten by a later
-        forward' -- when another training forward ran in between (the handle keeps one tape)."""
+        forward' -- when another training forward ran in between (the handle keeps one tape).  `on_group(name)` is invoked
+        each time every gradient of one top-level module has been enqueued (order: final_conv, final_res_block, ups.3..0, mid_block2,
+        mid_attn, mid_block1, downs.3..0, init_conv, time_mlp)."""
         L = _lib.lib()
         dev = d_eps.device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             g = d_eps.detach().float().contiguous()
-            _lib.check(L.tedm_unet_backward_gen(self._handle, g.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(),
-                                                stream, int(generation)), 'tedm_unet_backward')
+            handle = self._native['train'].handle
+            cb, errs = None, []
+            if on_group is not None:                     # called from inside the C backward each time a top-level module's gradients
+                def _mark(_user, name):                  # are enqueued (tedm_hip.h: tedm_unet_set_backward_callback)
+                    try:
+                        on_group(name.decode())
+                    except BaseException as e:           # never let an exception cross the C frame
+                        errs.append(e)
+                cb = _lib.BACKWARD_MARK_FN(_mark)
+                _lib.check(L.tedm_unet_set_backward_callback(handle, cb, None), 'set_backward_callback')
+            try:
+                _lib.check(L.tedm_unet_backward_gen(handle, g.data_ptr(), self._train_ws.data_ptr(), self._train_ws.numel(),
+                                                    stream, int(generation)), 'tedm_unet_backward')
+            finally:
+                if cb is not None:
+                    L.tedm_unet_set_backward_callback(handle, None, None)
+            if errs:
+                raise errs[0]
         return self._grad_views
 
     def _read_trace(self) -> Dict[str, Tensor]:

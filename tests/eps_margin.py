@@ -15,7 +15,7 @@ from oracle import unet_ref as O
 def main():
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     dev = torch.device('cuda:0')
-    m = Unet(64)
+    m = Unet(64, precision=os.environ.get('TEDM_PREC', 'f16f4'))     # the opt-in fast mode is what needs the margin scan
     load_synth_weights(m, seed=0)
     m = m.to(dev).eval()
     w = {k: v.detach().cpu() for k, v in m.state_dict().items()}

@@ -104,3 +104,71 @@ def test_two_rank_gloo_gradient_allreduce_equals_global_batch():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(err < 1e-5 for _, err in res), res
+
+
+def test_bucket_plan_covers_the_flat_buffer_in_backward_order():
+    from tedm_amd import dp
+    from tedm_amd.unet import Unet
+    m = Unet(64)
+    layout = m.grad_layout()
+    assert sorted(layout) == sorted((k, p.numel()) for k, p in m.named_parameters())
+    groups = []
+    for k, _ in layout:
+        if not groups or groups[-1] != dp.top_group(k):
+            groups.append(dp.top_group(k))
+    assert groups == list(reversed(dp.backward_group_order(4)))            # the buffer completes from its end to its start
+    total = sum(n for _, n in layout)
+    b = dp.plan_buckets(layout, 4, 4)
+    assert len(b) == 4 and b[0][2] == total and b[-1][1] == 0 and b[-1][0] == 'time_mlp'
+    assert all(x[1] == y[2] for x, y in zip(b, b[1:]))                     # contiguous slices, closed in completion order
+    order = dp.backward_group_order(4)
+    off, spans = 0, {}
+    for k, n in layout:
+        spans[k] = (off, off + n)
+        off += n
+    for g_last, lo, hi in b:                                               # a closed bucket holds only finished modules
+        done = order[:order.index(g_last) + 1]
+        for k, (a, e) in spans.items():
+            if a >= lo and e <= hi:
+                assert dp.top_group(k) in done, (k, g_last)
+    assert [x[0] for x in b] == ['ups.1', 'ups.0', 'mid_block1', 'time_mlp']
+    assert max(hi - lo for _, lo, hi in b) < 0.45 * total                   # ups.0 (14.6 M of 36.2 M) is the largest indivisible module
+    assert len(dp.plan_buckets(layout, 4, 1)) == 1 and 4 < len(dp.plan_buckets(layout, 4, 8)) <= 8    # modules are indivisible
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from tedm_amd import dp
+    from tedm_amd.unet import Unet
+    dist = dp.init('gloo')
+    m = Unet(32)
+    sizes = m.grad_layout()
+    total = sum(n for _, n in sizes)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(total, generator=g)
+    local_n, global_n = (3, 5) if rank == 0 else (2, 5)                    # ragged shards: scale by local_n / global_n
+    single = dp.allreduce_grads_(dist, local.clone(), local_n, global_n)
+    flat = local.clone()
+    red = dp.BucketedGradReducer(dist, flat, dp.plan_buckets(sizes, 4, 4), local_n, global_n)
+    for name in dp.backward_group_order(4):                                 # the sequence the native backward reports
+        red.on_group(name)
+    red.finish()
+    q.put((rank, bool(torch.equal(flat, single)), float(flat.double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_allreduce_is_bit_identical_to_single_buffer():
+    world, port = 2, 29635
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(eq for _, eq, _ in res), res
+    assert res[0][2] == res[1][2]                                           # both ranks hold the same reduced buffer

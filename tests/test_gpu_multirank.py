@@ -33,5 +33,10 @@ def test_two_ranks_denoise_line(built_lib):
 
 
 def test_two_ranks_train_line(built_lib):
+    """Train mode on 2 ranks: the bucketed all-reduce (4 slices launched from the backward's mark callback on a side stream)
+    must leave the same model as ONE all-reduce after the backward: equal loss after 3 optimizer steps."""
     d = run_bench(29542, '--mode', 'train')
-    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['final_loss'] > 0
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['final_loss'] > 0 and d['config']['grad_allreduce_buckets'] == 4
+    d1 = run_bench(29543, '--mode', 'train', '--buckets', '1')
+    assert d1['config']['grad_allreduce_buckets'] == 1
+    assert abs(d1['config']['final_loss'] - d['config']['final_loss']) <= 1e-6, (d1['config']['final_loss'], d['config']['final_loss'])
