@@ -723,7 +723,9 @@ namespace {
 size_t forward_workspace_bytes(const tedm_unet* h, int B, int H, int W, int flags, unsigned ext_taps) {
     Arena A;
     A.dry = true; A.keep = flags & TEDM_FWD_TRACE;
-    Fwd f{const_cast<tedm_unet*>(h), &A, nullptr, true, B, 0, true, nullptr, false};
+    // the arithmetic mode selects code paths with different allocation sequences (e.g. the fused linear-attention tail of
+    // F16F4): the dry run must replay the mode of the real call, not mode 0 (a first-fit arena is not monotone)
+    Fwd f{const_cast<tedm_unet*>(h), &A, nullptr, true, B, (flags >> TEDM_FWD_PREC_SHIFT) & 0xf, true, nullptr, false};
     static const float dummy_t = 0.f;
     static float ext_marker;                                 // never dereferenced in a dry run
     float* taps[TEDM_MAX_LEVELS] = {nullptr};
@@ -811,7 +813,7 @@ size_t tedm_unet_train_workspace_bytes(const tedm_unet* h, int B, int H, int W) 
     A.dry = true;
     Tape tape;
     tedm_unet* u = const_cast<tedm_unet*>(h);
-    Train tr{u, &A, nullptr, true, B, 0, &tape, Fwd{u, &A, nullptr, true, B, 0, true, nullptr, false}};
+    Train tr{u, &A, nullptr, true, B, h->prec, &tape, Fwd{u, &A, nullptr, true, B, h->prec, true, nullptr, false}};
     static const float dummy_t = 0.f;
     if (tr.forward(nullptr, &dummy_t, H, W, nullptr) != TEDM_OK) return 0;
     if (tr.backward(nullptr) != TEDM_OK) return 0;
@@ -953,7 +955,7 @@ size_t tedm_unet_module_workspace_bytes(const tedm_unet* h, const char* module, 
     A.dry = true;
     static const float dummy = 0.f;
     const int C1 = m.res ? m.res->cin : m.attn->C;
-    if (run_module(const_cast<tedm_unet*>(h), m, A, nullptr, true, nullptr, C1, nullptr, 0, &dummy, B, H, W, nullptr, 0) != TEDM_OK) return 0;
+    if (run_module(const_cast<tedm_unet*>(h), m, A, nullptr, true, nullptr, C1, nullptr, 0, &dummy, B, H, W, nullptr, h->prec) != TEDM_OK) return 0;
     return A.peak + 256;
 }
 
