@@ -30,6 +30,23 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
                    const float* add, const float* add_a, const float* add_b,
                    float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream);
 int tedm_op_conv2d_stats_entries(int Cout, int k, int stride, int Ho, int Wo);
+/* Q16 activation storage (tedm_amd/csrc/common.h): int16 data [B][H][W][C] followed by one power-of-two scale byte per block
+ * (row, 32-column tile, half, channel) = the 16 pixels one lane of the conv's MFMA accumulator holds.  The fast inference mode stores
+ * the two conv outputs inside a ResnetBlock this way on the HBM-bound levels (tedm_set_tuning("act_q16", 0) turns it off;
+ * "act_q16_max_c" bounds the block width it applies to).  Test surface:
+ *   tedm_q16_bytes: size of the buffer of a (B, H, W, C) tensor (C % 8 == 0), 0 on bad arguments;
+ *   tedm_q16_encode / tedm_q16_decode: fp32 NHWC <-> Q16; decode(encode(x)) is the format's rounding;
+ *   tedm_op_conv2d_q16: one k x k (3 or 1) stride-1 conv; q16_flags bit 0: x is Q16 (needs the GroupNorm prologue coefficients),
+ *   bit 1: out is Q16, bit 2: add is Q16 (the silu(add_a * add + add_b) resnet addend); emits the sum / sum-of-squares slab when `stats`;
+ *   tedm_op_resblock_out_q16: out = silu(ga * y + gb) + x with y in Q16 (+ channel-LayerNorm statistics when lnstats != NULL). */
+size_t tedm_q16_bytes(int B, int H, int W, int C);
+int tedm_q16_encode(const float* x, void* q, int B, int H, int W, int C, void* stream);
+int tedm_q16_decode(const void* q, float* x, int B, int H, int W, int C, void* stream);
+int tedm_op_conv2d_q16(const void* x, int C, int B, int H, int W, const float* weight_oihw, const float* bias, int Cout, int k,
+                       const float* gn_a, const float* gn_b, const void* add, const float* add_a, const float* add_b, void* out,
+                       float* stats, int* stats_entries, int prec, int q16_flags, void* stream);
+int tedm_op_resblock_out_q16(const void* y_q16, const float* ga, const float* gb, const float* x, float* out, float* lnstats, int B,
+                             int H, int W, int C, void* stream);
 /* Tuning harness: the same conv, weights packed once, 2 warm-up launches, then `iters` launches bracketed by HIP events on
  * `stream`; *ms_per_launch = their mean duration. */
 int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B, int H, int W,

@@ -74,6 +74,12 @@ _SIGNATURES = {
                                   C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                   C.POINTER(C.c_int), C.c_int, _P]),
     'tedm_op_conv2d_stats_entries': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_q16_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'tedm_q16_encode': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'tedm_q16_decode': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'tedm_op_conv2d_q16': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
+                                      C.POINTER(C.c_int), C.c_int, C.c_int, _P]),
+    'tedm_op_resblock_out_q16': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tedm_op_conv2d_bench': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
                                         C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     'tedm_op_conv2d_backward': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

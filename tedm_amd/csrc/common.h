@@ -131,6 +131,49 @@ TEDM_DEVFN uint4 split8_f16_res_sat(const float (&v)[8], float (&lo)[8]) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// ---- Q16: 16-bit block-integer activation storage -----------------------------------------------------------------------------
+// The two conv outputs inside a ResnetBlock are written once and read once (by the GroupNorm prologue of the next kernel).  On
+// the HBM-bound levels of the fast inference mode they are stored as int16 with one power-of-two scale per BLOCK, where a block
+// is what ONE LANE of the producing conv's MFMA accumulator holds: 16 pixels of one channel --
+//     block (b, y, xt, hh, c) = pixels x in [32 xt, 32 xt + 32) of row y with ((x >> 2) & 1) == hh, channel c
+// -- so the producer finds the block maximum and rounds without any cross-lane operation, and the res_conv epilogue that adds
+// such a tensor decodes lane-locally too.  Buffer of a (B, H, W, C) tensor (C % 8 == 0):
+//     int16  q[B][H][W][C]                  value = q * 2^(Eb - 127),  q in [-32767, 32767]
+//     uint8  Eb[B][H][TX][2][C]              TX = ceil(W / 32); Eb = 0 <=> the block is all zero (or below 2^-112)
+// (scales right behind the data: q16_bytes).  Relative to the block's maximum the rounding step is 2^-15..2^-14: 16 significant
+// bits where fp16 has 11.  Measured cost on eps (tests/precision_study.py branch): <= 1e-4 in quadrature at 256x256 (fp16 storage:
+// 5e-4), DESIGN.md section 2.  Decoding is EXACT arithmetic (integer * power of two), so a consumer of Q16 data computes bit
+// for bit what it would compute from the decoded fp32 tensor.
+TEDM_DEVFN size_t q16_scale_offset(int B, int H, int W, int C) { return (size_t)2 * B * H * W * C; }      // bytes
+TEDM_DEVFN size_t q16_scale_index(long long row /* b*H + y */, int x, int W, int C) {
+    return (((size_t)row * ((W + 31) >> 5) + (x >> 5)) * 2 + ((x >> 2) & 1)) * C;
+}
+// `amax`: maximum |v| over the block.  Returns the scale byte Eb and the encode scale 2^(14-E) (0 when flushed).
+TEDM_DEVFN unsigned q16_exponent(float amax, float& enc) {
+    const unsigned eb32 = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;      // biased fp32 exponent of amax
+    const bool flush = eb32 < 15u;
+    const unsigned ebc = eb32 > 254u ? 254u : eb32;                                // inf / nan saturate
+    enc = flush ? 0.f : __builtin_bit_cast(float, (268u - ebc) << 23);
+    return flush ? 0u : ebc - 14u;
+}
+// round to nearest even, saturate at +-32767; the int16 is the LOW HALF of the result
+TEDM_DEVFN unsigned q16_word(float v, float enc) {
+    const float t = __builtin_amdgcn_fmed3f(v * enc, -32767.f, 32767.f);
+    return __builtin_bit_cast(unsigned, t + 12582912.f);                           // 1.5 * 2^23: the integer sits in the low mantissa bits
+}
+TEDM_DEVFN float q16_scale(unsigned eb) { return __builtin_bit_cast(float, eb << 23); }
+// 8 consecutive channels of one pixel: data dwords d, scale bytes sc (channel k = byte k)
+TEDM_DEVFN void q16_decode8(const uint4 d, const uint2 sc, float (&v)[8]) {
+    const unsigned w[4] = {d.x, d.y, d.z, d.w};
+    const unsigned s2[2] = {sc.x, sc.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = (int)w[i];
+        v[2 * i] = (float)((m << 16) >> 16) * q16_scale((s2[i >> 1] >> (16 * (i & 1))) & 0xffu);
+        v[2 * i + 1] = (float)(m >> 16) * q16_scale((s2[i >> 1] >> (16 * (i & 1) + 8)) & 0xffu);
+    }
+}
+
 TEDM_DEVFN float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -149,7 +192,7 @@ TEDM_DEVFN float group_sum(float v, int width) {
 
 // ---- conv_igemm.hip -------------------------------------------------------------------
 // Prologue applied to the conv input while it is staged into LDS.
-enum { PRO_NONE = 0, PRO_GN = 1, PRO_LN = 2 };
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_LN = 2, PRO_GNQ = 3 };   // PRO_GNQ: PRO_GN on a Q16-stored source (one source, C % 8 == 0)
 // Per-output-channel statistics the epilogue can emit (deterministic slabs, no atomics).
 enum { STATS_NONE = 0, STATS_SUMSQ = 1, STATS_MAX = 2 };
 
@@ -175,6 +218,8 @@ struct ConvArgs {
     int nk16;                      // (C1+C2)/16
     int prec;                      // TEDM_PREC_*
     int prio_mode;                 // 0 none, 1: waves in even SIMD slots run at s_setprio 1 (filled by the launcher)
+    int out_q16;                   // `out` is a Q16 buffer (int16 data + block scales, see q16_decode8): Cout % 32 == 0, no addend, no parity form
+    int add_q16;                   // `add` is a Q16 buffer (only with add_a / add_b: the silu(a*add+b) resnet addend)
     unsigned long long* trace;     // diagnostic builds (-DTEDM_DIAG_TRACE) only: per-wave phase timestamps
     // ups == 3 (KH = 2, template PAD < 0): the four parity convolutions of a nearest-x2 upsample + 3x3 conv.  (H, W) =
     // (Ho, Wo) is the low-resolution grid; "tile" index t = 4 * spatial tile + parity (a, b); parity weights are wpk_pstride

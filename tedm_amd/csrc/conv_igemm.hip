@@ -87,8 +87,11 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
     const int id = effective_tile(a, KH, stride, ups);
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
-    snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
-             ks, nbuf, pro, a.prec);
+    const int qio = (a.out_q16 ? 1 : 0) | (a.add_q16 ? 2 : 0);
+    if (qio) snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
+                      ks, nbuf, pro, a.prec, qio);
+    else snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
+                  ks, nbuf, pro, a.prec);
     if (ups == 3) snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-1,0,%d,%d,%d,%d,2,%d,%d>", t.wm, t.wn, t.mt, ks, pro, a.prec);
 }
 

@@ -451,6 +451,92 @@ __global__ __launch_bounds__(256) void resblock_out_kernel(const float* __restri
     }
 }
 
+// The same on a Q16-stored y (common.h): a lane owns 8 consecutive channels of a pixel (16 bytes of int16 + 8 scale bytes), C / 8
+// lanes (a power of two <= 64) share the pixel.  Decoding is exact, so the result equals resblock_out on the decoded tensor.
+__global__ __launch_bounds__(256) void resblock_out_q16_kernel(const short* __restrict__ y, const unsigned char* __restrict__ ysc,
+                                                               const float* __restrict__ ga, const float* __restrict__ gb,
+                                                               const float* __restrict__ x, float* __restrict__ out,
+                                                               float* __restrict__ lnstats, long long P, long long hw, int W, int C, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
+        const long long p = p0 + sub;
+        const bool ok = p < P;
+        const int n = ok ? (int)(p / hw) : 0;
+        const int c = q * 8;
+        float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float s = 0.f;
+        if (ok) {
+            float yy[8];
+            const long long row = p / W;
+            q16_decode8(*(const uint4*)(y + (size_t)p * C + c), *(const uint2*)(ysc + q16_scale_index(row, (int)(p - row * W), W, C) + c), yy);
+            const float4 a0 = *(const float4*)(ga + (size_t)n * C + c), a1 = *(const float4*)(ga + (size_t)n * C + c + 4);
+            const float4 b0 = *(const float4*)(gb + (size_t)n * C + c), b1 = *(const float4*)(gb + (size_t)n * C + c + 4);
+            const float4 x0 = *(const float4*)(x + (size_t)p * C + c), x1 = *(const float4*)(x + (size_t)p * C + c + 4);
+            const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const float xx[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = silu_f(fmaf(aa[e], yy[e], bb[e])) + xx[e];
+            *(float4*)(out + (size_t)p * C + c) = make_float4(val[0], val[1], val[2], val[3]);
+            *(float4*)(out + (size_t)p * C + c + 4) = make_float4(val[4], val[5], val[6], val[7]);
+        }
+        s = ((val[0] + val[1]) + (val[2] + val[3])) + ((val[4] + val[5]) + (val[6] + val[7]));
+        if (lnstats) {                                         // uniform branch
+            const float mean = group_sum(s, lpp) / (float)C;
+            float d2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = val[e] - mean; d2 = fmaf(d, d, d2); }
+            const float var = group_sum(d2, lpp) / (float)C;
+            const float rstd = rsqrtf(var + 1e-5f);
+            if (ok && q == 0) *(float2*)(lnstats + (size_t)p * 2) = make_float2(rstd, mean * rstd);
+        }
+    }
+}
+
+// fp32 NHWC <-> Q16 (test helpers and the format's reference encoder): one thread per block (row, 32-column tile, half, channel)
+__global__ __launch_bounds__(256) void q16_encode_kernel(const float* __restrict__ x, short* __restrict__ q, unsigned char* __restrict__ sc,
+                                                         long long rows, int W, int C) {
+    const int TX = (W + 31) >> 5;
+    const long long nblk = rows * TX * 2 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int hh = (int)(t & 1); t >>= 1;
+        const int xt = (int)(t % TX);
+        const long long row = t / TX;
+        float v[16];
+        unsigned mx = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int xx = xt * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+            v[k] = xx < W ? x[((size_t)row * W + xx) * C + c] : 0.f;
+            const unsigned ab = __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu;
+            mx = mx > ab ? mx : ab;
+        }
+        float enc;
+        const unsigned eb = q16_exponent(__builtin_bit_cast(float, mx), enc);
+        sc[i] = (unsigned char)eb;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int xx = xt * 32 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+            if (xx < W) q[((size_t)row * W + xx) * C + c] = (short)q16_word(v[k], enc);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void q16_decode_kernel(const short* __restrict__ q, const unsigned char* __restrict__ sc, float* __restrict__ x,
+                                                         long long rows, int W, int C) {
+    const long long pieces = rows * W * (C / 8);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (C / 8)) * 8;
+        const long long p = i / (C / 8), row = p / W;
+        float v[8];
+        q16_decode8(*(const uint4*)(q + (size_t)p * C + c), *(const uint2*)(sc + q16_scale_index(row, (int)(p - row * W), W, C) + c), v);
+        *(float4*)(x + (size_t)p * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(x + (size_t)p * C + c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // channel-LayerNorm statistics only (models/unet_model.py:52-61): stats[p] = (rstd, mean*rstd)
 template <int V>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ lnstats,
@@ -744,6 +830,36 @@ int op_resblock_out(const float* y, const float* ga, const float* gb, const floa
     const long long P = (long long)B * hw;
     DISPATCH_V(m.v, resblock_out_kernel, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, y, ga, gb, x, out, lnstats, P, hw,
                C, m.lpp);
+    return LAUNCH_OK();
+}
+
+size_t q16_bytes(int B, int H, int W, int C) { return (size_t)2 * B * H * W * C + (size_t)B * H * ((W + 31) / 32) * 2 * C; }
+
+int op_resblock_out_q16(const void* y, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
+                        int B, int H, int W, int C, hipStream_t st) {
+    const int lpp = C / 8;
+    if (C % 8 || lpp < 1 || lpp > 64 || (lpp & (lpp - 1))) return TEDM_EINVAL;       // C in {8, 16, ..., 512}, a power of two
+    const long long hw = (long long)H * W, P = (long long)B * hw;
+    hipLaunchKernelGGL(resblock_out_q16_kernel, dim3(pix_grid(P, lpp)), dim3(256), 0, st, (const short*)y,
+                       (const unsigned char*)y + (size_t)2 * P * C, ga, gb, x, out, lnstats, P, hw, W, C, lpp);
+    return LAUNCH_OK();
+}
+int op_q16_encode(const float* x, void* q, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8) return TEDM_EINVAL;
+    const long long rows = (long long)B * H, nblk = rows * ((W + 31) / 32) * 2 * C;
+    long long blocks = (nblk + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(q16_encode_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, x, (short*)q,
+                       (unsigned char*)q + (size_t)2 * rows * W * C, rows, W, C);
+    return LAUNCH_OK();
+}
+int op_q16_decode(const void* q, float* x, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8) return TEDM_EINVAL;
+    const long long rows = (long long)B * H, pieces = rows * W * (C / 8);
+    long long blocks = (pieces + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(q16_decode_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, (const short*)q,
+                       (const unsigned char*)q + (size_t)2 * rows * W * C, x, rows, W, C);
     return LAUNCH_OK();
 }
 

@@ -15,6 +15,12 @@ int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long
                    hipStream_t st);
 int op_resblock_out(const float* y, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
                     int B, long long hw, int C, hipStream_t st);
+// Q16 activation buffers (common.h): int16 data + block-scale bytes; C / 8 a power of two <= 64 for resblock_out
+size_t q16_bytes(int B, int H, int W, int C);
+int op_resblock_out_q16(const void* y_q16, const float* ga, const float* gb, const float* x, float* out, float* lnstats,
+                        int B, int H, int W, int C, hipStream_t st);
+int op_q16_encode(const float* x, void* q, int B, int H, int W, int C, hipStream_t st);       // C % 8 == 0
+int op_q16_decode(const void* q, float* x, int B, int H, int W, int C, hipStream_t st);
 int op_ln_stats(const float* x, float* lnstats, long long P, int C, hipStream_t st);
 int op_ln_res(const float* z, const float* g, const float* x, float* out, long long P, int C, hipStream_t st);
 int op_final_conv(const float* x, const float* w, const float* bias, float* out_nchw, int B, long long hw, int C,

@@ -177,6 +177,14 @@ struct Profiler {
     void reset() { (void)collect(); entries.clear(); idx.clear(); }
 };
 Profiler g_prof;
+int g_bench_q16 = 0;
+int g_act_q16 = 0;         // tedm_set_tuning("act_q16", 0|1): Q16 (16-bit block-integer, common.h) storage of the two conv outputs inside a
+                           // ResnetBlock under TEDM_PREC_F16F4 inference; takes effect at the next forward (no repack).  OFF by default:
+                           // measured on MI355X (profiles/r03_q16_experiment.txt) it costs nothing in eps (3.25e-4 vs 3.32e-4) and
+                           // halves those tensors' bytes, but the 64-channel 3x3 convs are latency-bound, not HBM-bound -- the ~6
+                           // VALU operations per value of the encoder / decoder cost more (conv1 +8 %, conv2 +14 %) than the bytes
+                           // return (resblock_out -19 %, res_conv -3 %): 16.66 ms per step against 16.45 ms without it.
+int g_act_q16_max_c = 128; // ... for blocks with at most this many channels (the HBM-bound levels).  tedm_set_tuning("act_q16_max_c", 0..512)
 int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1|2) BEFORE tedm_unet_pack: which convolutions run ONE fp16 product under
                            // F16F4 (TEDM_PREC_FP16).  1 (default): the two 3x3 convs inside every ResnetBlock below the full
                            // resolution (GroupNorm renormalises their output; per-conv eps cost 0.2-1e-4, tests/precision_study.py
@@ -357,10 +365,11 @@ inline bool prec_ok(int prec) { return prec == TEDM_PREC_BF16X3 || prec == TEDM_
 
 struct Fwd {
     tedm_unet* u; Arena* A; hipStream_t st; bool dry; int B; int prec; bool film; float* filmbuf; bool tracing;
+    bool q16 = true;        // Q16 branch storage allowed (the inference forward; the training tape keeps fp32)
 
     int conv(const ConvW& w, const float* x1, int C1, const float* x2, int C2, int H, int W, int Ho, int Wo, float* out,
              int stride, int ups, int pro, const float* pa, const float* pb, const float* add, const float* add_a,
-             const float* add_b, float* stats, int stats_mode) {
+             const float* add_b, float* stats, int stats_mode, int q16 = 0 /* bit 0: `out` is Q16, bit 1: `add` is Q16 */) {
         if (dry) return TEDM_OK;
         ConvArgs a{};
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = w.cout;
@@ -369,6 +378,9 @@ struct Fwd {
         if (ups == 1 && w.wpk_up && g_conv_up_split && !x2) { a.wpk = w.wpk_up; k = 2; ups = 3; } a.bias = w.has_bias ? u->P(w.key + ".bias") : nullptr;
         a.pro_a = pa; a.pro_b = pb; a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b;
         a.stats = stats; a.stats_mode = stats_mode; a.prec = conv_prec(w, prec);
+        a.out_q16 = q16 & 1; a.add_q16 = (q16 >> 1) & 1;
+        if ((q16 || pro == PRO_GNQ) && (w.cout % 32 || (a.prec != TEDM_PREC_F16F4 && a.prec != TEDM_PREC_FP16) || stride != 1 || ups || (w.k != 3 && w.k != 1)))
+            return fail(TEDM_EINVAL, "Q16 activation storage is not available for %s", w.key.c_str());
         if (g_prof.level >= 1) {
             char label[160];
             conv_kernel_label(a, k, stride, ups, pro, label, sizeof(label));
@@ -378,7 +390,8 @@ struct Fwd {
             }
             const double cin = C1 + C2;
             g_prof.begin(label, 2.0 * B * Ho * Wo * w.cout * cin * k * k,       // executed MACs (parity form: 4 taps per output)
-                         4.0 * B * ((double)H * W * cin + (double)Ho * Wo * w.cout * (add ? 2 : 1)), st);
+                         1.0 * B * ((double)H * W * cin * (pro == PRO_GNQ ? 2 : 4) +
+                                    (double)Ho * Wo * w.cout * ((a.out_q16 ? 2 : 4) + (add ? (a.add_q16 ? 2 : 4) : 0))), st);
         }
         const int rc = conv_launch(a, k, stride, ups, pro, st);
         if (g_prof.level >= 1) g_prof.end(st);
@@ -397,15 +410,19 @@ struct Fwd {
         const int C = r.cout;
         const int E = conv_stats_entries(3, 1, C, H, W);
         float* slab = A->alloc((size_t)B * E * C * 2);
-        float* y1 = A->alloc((size_t)B * hw * C);
+        // Q16 storage of the two branch tensors (written once, read once through a GroupNorm prologue) on the HBM-bound levels
+        // of the fast inference mode: 2 bytes per element instead of 4, +1e-4 on eps in quadrature (common.h)
+        const bool q = q16 && g_act_q16 && prec == TEDM_PREC_F16F4 && C <= g_act_q16_max_c && C % 32 == 0 && (C & (C - 1)) == 0 && C <= 512;
+        const size_t qf = (q16_bytes(B, H, W, C) + 3) / 4;                       // floats of a Q16 buffer
+        float* y1 = A->alloc(q ? qf : (size_t)B * hw * C);
         float* ga = A->alloc((size_t)B * C);
         float* gb = A->alloc((size_t)B * C);
-        CHECK(conv(r.c1, x1, C1, x2, C2, H, W, H, W, y1, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
+        CHECK(conv(r.c1, x1, C1, x2, C2, H, W, H, W, y1, 1, 0, PRO_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, slab, STATS_SUMSQ, q ? 1 : 0));
         OP("gn_finalize", 0.0, 8.0 * B * E * C,
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block1.norm.weight"),
                           u->P(r.pre + ".block1.norm.bias"), film ? filmbuf + r.film_off : nullptr, u->film_J, ga, gb, nullptr, st));
-        float* y2 = A->alloc((size_t)B * hw * C);
-        CHECK(conv(r.c2, y1, C, nullptr, 0, H, W, H, W, y2, 1, 0, PRO_GN, ga, gb, nullptr, nullptr, nullptr, slab, STATS_SUMSQ));
+        float* y2 = A->alloc(q ? qf : (size_t)B * hw * C);
+        CHECK(conv(r.c2, y1, C, nullptr, 0, H, W, H, W, y2, 1, 0, q ? PRO_GNQ : PRO_GN, ga, gb, nullptr, nullptr, nullptr, slab, STATS_SUMSQ, q ? 1 : 0));
         A->release(y1);
         OP("gn_finalize", 0.0, 8.0 * B * E * C,
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
@@ -413,8 +430,11 @@ struct Fwd {
         float* o = A->alloc((size_t)B * hw * C);
         float* ln = lnstats ? A->alloc((size_t)B * hw * 2) : nullptr;
         if (r.has_res) {
-            CHECK(conv(r.res, x1, C1, x2, C2, H, W, H, W, o, 1, 0, PRO_NONE, nullptr, nullptr, y2, ga, gb, nullptr, STATS_NONE));
+            CHECK(conv(r.res, x1, C1, x2, C2, H, W, H, W, o, 1, 0, PRO_NONE, nullptr, nullptr, y2, ga, gb, nullptr, STATS_NONE, q ? 2 : 0));
             if (ln) OP("ln_stats", 0.0, 4.0 * B * hw * C, op_ln_stats(o, ln, (long long)B * hw, C, st));
+        } else if (q) {
+            OP(ln ? "resblock_out_q16+ln_stats" : "resblock_out_q16", 0.0, 10.0 * B * hw * C,
+               op_resblock_out_q16(y2, ga, gb, x1, o, ln, B, H, W, C, st));
         } else {
             OP(ln ? "resblock_out+ln_stats" : "resblock_out", 0.0, 12.0 * B * hw * C, op_resblock_out(y2, ga, gb, x1, o, ln, B, hw, C, st));
         }
@@ -1084,16 +1104,57 @@ int tedm_set_tuning(const char* key, int value) {
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
     if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
     if (!strcmp(key, "deep_fp16") && value >= 0 && value <= 2) { g_deep_fp16 = value; return TEDM_OK; }
+    if (!strcmp(key, "act_q16") && (value == 0 || value == 1)) { g_act_q16 = value; return TEDM_OK; }
+    if (!strcmp(key, "act_q16_max_c") && value >= 0 && value <= 512) { g_act_q16_max_c = value; return TEDM_OK; }
+    if (!strcmp(key, "bench_q16") && value >= 0 && value <= 7) { g_bench_q16 = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
 }
 
 // ---- op-level entry point (tests): one nn.Conv2d through the implicit-GEMM kernel -------------
+namespace {
+int op_conv2d_impl(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
+                   const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
+                   const float* ln_g, const float* ln_stats, const float* add, const float* add_a, const float* add_b,
+                   float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream, int q16_flags);
+}
 int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
                    const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
                    const float* ln_g, const float* ln_stats, const float* add, const float* add_a, const float* add_b,
                    float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream) {
+    return op_conv2d_impl(x1, C1, x2, C2, B, H, W, weight_oihw, bias, Cout, k, stride, upsample, gn_a, gn_b, ln_g, ln_stats, add,
+                          add_a, add_b, out, stats, stats_mode, stats_entries, prec, stream, 0);
+}
+int tedm_op_conv2d_q16(const void* x, int C, int B, int H, int W, const float* weight_oihw, const float* bias, int Cout, int k,
+                       const float* gn_a, const float* gn_b, const void* add, const float* add_a, const float* add_b, void* out,
+                       float* stats, int* stats_entries, int prec, int q16_flags, void* stream) {
+    if ((q16_flags & 1) && !gn_a) return fail(TEDM_EINVAL, "a Q16 source needs the GroupNorm prologue coefficients");
+    return op_conv2d_impl((const float*)x, C, nullptr, 0, B, H, W, weight_oihw, bias, Cout, k, 1, 0, gn_a, gn_b, nullptr, nullptr,
+                          (const float*)add, add_a, add_b, (float*)out, stats, STATS_SUMSQ, stats_entries, prec, stream, q16_flags);
+}
+size_t tedm_q16_bytes(int B, int H, int W, int C) { return (B < 1 || H < 1 || W < 1 || C < 8 || C % 8) ? 0 : q16_bytes(B, H, W, C); }
+int tedm_q16_encode(const float* x, void* q, int B, int H, int W, int C, void* stream) {
+    g_err[0] = 0;
+    if (!x || !q || C % 8) return fail(TEDM_EINVAL, "q16 encode: C %% 8 == 0 required");
+    return op_q16_encode(x, q, B, H, W, C, (hipStream_t)stream) == TEDM_OK ? TEDM_OK : fail(TEDM_EHIP, "launch failed");
+}
+int tedm_q16_decode(const void* q, float* x, int B, int H, int W, int C, void* stream) {
+    g_err[0] = 0;
+    if (!x || !q || C % 8) return fail(TEDM_EINVAL, "q16 decode: C %% 8 == 0 required");
+    return op_q16_decode(q, x, B, H, W, C, (hipStream_t)stream) == TEDM_OK ? TEDM_OK : fail(TEDM_EHIP, "launch failed");
+}
+int tedm_op_resblock_out_q16(const void* y_q16, const float* ga, const float* gb, const float* x, float* out, float* lnstats, int B,
+                             int H, int W, int C, void* stream) {
+    g_err[0] = 0;
+    const int rc = op_resblock_out_q16(y_q16, ga, gb, x, out, lnstats, B, H, W, C, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "resblock_out_q16: C / 8 must be a power of two <= 64 (got C = %d)", C);
+}
+namespace {
+int op_conv2d_impl(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
+                   const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
+                   const float* ln_g, const float* ln_stats, const float* add, const float* add_a, const float* add_b,
+                   float* out, float* stats, int stats_mode, int* stats_entries, int prec, void* stream, int q16_flags) {
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     const int Cin = C1 + C2;
@@ -1117,7 +1178,9 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
         a.wpk = wpk; a.bias = bias;
         int pro = PRO_NONE;
-        if (gn_a) { pro = PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        if (gn_a) { pro = (q16_flags & 1) ? PRO_GNQ : PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        a.out_q16 = (q16_flags >> 1) & 1; a.add_q16 = (q16_flags >> 2) & 1;
+        if (q16_flags && (Cout % 32 || C1 % 8 || (prec != TEDM_PREC_F16F4 && prec != TEDM_PREC_FP16))) { (void)hipFree(wpk); return fail(TEDM_EINVAL, "Q16: Cout %% 32, C %% 8, prec F16F4 / FP16"); }
         else if (ln_g) { pro = PRO_LN; a.pro_a = ln_g; a.pro_b = ln_stats; }
         a.out = out; a.add = add; a.add_a = add_a; a.add_b = add_b; a.stats = stats; a.stats_mode = stats ? stats_mode : STATS_NONE;
         a.prec = prec;
@@ -1147,12 +1210,14 @@ int tedm_op_conv2d(const float* x1, int C1, const float* x2, int C2, int B, int 
     (void)hipFree(wpk);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_conv2d failed (%d)", rc);
 }
+}  // namespace
 
 // ---- tuning harness: time `iters` launches of one conv (weights packed once, HIP events on `stream`) ----
 int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, const float* weight_oihw,
                          const float* bias, int Cout, int k, int stride, int upsample, const float* gn_a, const float* gn_b,
                          const float* add, float* out, float* stats, int stats_mode, int prec, int iters, float* ms_per_launch,
                          void* stream) {
+    const int q16_flags = g_bench_q16;                   // tedm_set_tuning("bench_q16", bits): time the Q16 instances (bit 0 source, 1 output, 2 addend)
     g_err[0] = 0;
     hipStream_t st = (hipStream_t)stream;
     const int Cin = C1 + C2;
@@ -1177,7 +1242,9 @@ int tedm_op_conv2d_bench(const float* x1, int C1, const float* x2, int C2, int B
         a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
         a.wpk = wpk; a.bias = bias;
         int pro = PRO_NONE;
-        if (gn_a) { pro = PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        if (gn_a) { pro = (q16_flags & 1) ? PRO_GNQ : PRO_GN; a.pro_a = gn_a; a.pro_b = gn_b; }
+        a.out_q16 = (q16_flags >> 1) & 1; a.add_q16 = (q16_flags >> 2) & 1;
+        if (q16_flags && (Cout % 32 || C1 % 8 || (prec != TEDM_PREC_F16F4 && prec != TEDM_PREC_FP16))) { (void)hipFree(wpk); return fail(TEDM_EINVAL, "Q16: Cout %% 32, C %% 8, prec F16F4 / FP16"); }
         a.out = out; a.add = add; a.stats = stats; a.stats_mode = stats ? stats_mode : STATS_NONE; a.prec = prec;
         for (int i = 0; i < 2 && rc == TEDM_OK; ++i) rc = conv_launch(a, k, stride, upsample, pro, st);
         (void)hipEventRecord(e0, st);

@@ -34,6 +34,20 @@ def minifloat(x, ebits, mbits, bias, vmax):
     return q.clamp(-vmax, vmax)
 
 
+def q15e(x, block=8, bits=15):
+    """Block integer storage along the channel axis (dim 1): `bits`-bit signed integers with one shared power-of-two scale per
+    `block` consecutive channels of a pixel (the exponent travels in the stolen LSBs of the block's eight int16: 16 B per 8
+    channels, self-contained).  scale = 2^(floor(log2 amax) + 2 - bits), round to nearest, saturating."""
+    xm = x.movedim(1, -1)
+    C = xm.shape[-1]
+    xb = xm.reshape(*xm.shape[:-1], C // block, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True).clamp(min=2.0 ** -100)
+    sc = torch.exp2(torch.floor(torch.log2(amax)) + 2 - bits)
+    lim = 2.0 ** (bits - 1) - 1
+    q = torch.round(xb / sc).clamp(-lim, lim) * sc
+    return q.reshape(*xm.shape).movedim(-1, 1)
+
+
 def bf8(x): return minifloat(x, 5, 2, 15, 57344.0)
 def fp8(x): return minifloat(x, 4, 3, 7, 448.0)
 
@@ -224,7 +238,7 @@ def storage_study(size=64):
     ref = O.unet_forward(w, x_t, t)
     res0, la0, fa0 = O.resnet_block, O.linear_attention, O.full_attention
     for arith in ('fp32', 'f16f4'):
-        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('bf16', bf16)):
+        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('bf16', bf16), ('q15e8', q15e), ('q16b32', lambda v: q15e(v, 32, 16))):
             base = make_conv(arith) if arith != 'fp32' else _conv
 
             def conv(x, ww, b=None, *a, _base=base, _rnd=rnd, **k):
@@ -257,7 +271,7 @@ def branch_storage_study(size=64):
     ref = O.unet_forward(w, x_t, t)
     block0 = O.block
     for arith in ('fp32', 'f16f4'):
-        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('bf16', bf16)):
+        for name, rnd in (('fp32', lambda v: v), ('fp16', fp16), ('q15e8', q15e), ('q16b32', lambda v: q15e(v, 32, 16))):
             def blk(p, pre, x, groups, scale_shift, _rnd=rnd):
                 y = F.conv2d(x, p[pre + '.proj.weight'], p[pre + '.proj.bias'], padding=1)
                 if WHICH is None or pre.endswith(WHICH):
