@@ -238,6 +238,7 @@ def main() -> None:
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=1, help='inference: sub-batches on this many HIP streams (Unet.streams; bit-identical results)')
     ap.add_argument('--buckets', type=int, default=4, help='--mode train: gradient all-reduce buckets launched under the backward (1 = one all-reduce after it)')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
     ap.add_argument('--tile-wide', type=int, default=None, help='tuning: conv tile id for Cout>=128')
@@ -280,6 +281,7 @@ def main() -> None:
     if args.prec is None:          # the benchmark opts into the fast inference arithmetic (gated by the eps check below); training: bf16x3
         args.prec = dm.model.train_precision if args.mode == 'train' else 'f16f4'
     dm.model.precision = dm.model.train_precision = args.prec
+    dm.model.streams = args.streams
 
     g = torch.Generator().manual_seed(1234 + rank)
     x0 = torch.rand(B, 1, S, S, generator=g).to(dev)
@@ -362,7 +364,7 @@ def main() -> None:
                                           '1.5 bf16-rate MFMA issues per 16 channels; the two 3x3 convolutions INSIDE every ResnetBlock below the full '
                                           'resolution (downs.1-3, mid, ups.0-2: 28 of the 46 k x k convolutions) run one fp16 product; '
                                           'fp32 accumulate, fp32 activations in HBM'}[args.prec],
-                   'parallelism': f'dp{world} (batch sharded, no data-path collective)'},
+                   'parallelism': f'dp{world} (batch sharded, no data-path collective)', 'hip_streams_per_gpu': args.streams},
     }
 
     if rank == 0:

@@ -22,7 +22,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -243,6 +243,13 @@ class Unet(nn.Module):
         self._native: Dict[str, _Native] = {'infer': _Native(), 'train': _Native()}
         self._workspace: Optional[Tensor] = None
         self._train_ws: Optional[Tensor] = None
+        # Inference batches of >= `stream_min_batch` images can be cut into `streams` sub-batches that run on that many side
+        # HIP streams (one workspace each, the same handle and packed weights): the tails and launch gaps of one sub-batch's kernels
+        # are filled by the other's.  Results are bit-identical (the UNet has no cross-sample op).  Measured on MI355X at
+        # 32x256x256: 2 streams -3.8 % (16.19 -> 15.58 ms), 3 streams the same, 4 streams +5 % (sub-batches too small).
+        self.streams = int(os.environ.get('TEDM_STREAMS') or kwargs.get('streams') or 1)
+        self.stream_min_batch = 16
+        self._side: List[Tuple] = []            # [(torch.cuda.Stream, workspace tensor or None)] per device, lazily
         self.grad_flat: Optional[Tensor] = None     # one flat fp32 buffer holding every parameter gradient
         self._grad_views: Dict[str, Tensor] = {}
         self._grad_handle = None
@@ -396,22 +403,48 @@ class Unet(nn.Module):
                 if tin.numel() != B:
                     raise ValueError(f'timestep must have {B} elements, got {tin.numel()}')
             flags = self._flags(taps_only, trace)
-            need = L.tedm_unet_workspace_bytes(handle, B, H, W, flags)
-            if need == 0:
-                _lib.check(-1, f'workspace sizing for input {tuple(x.shape)}')
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             eps = None if taps_only else torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=dev)
             taps = None
-            feat_ptrs = None
             if want_taps or taps_only:
                 taps = [torch.empty(s, dtype=torch.float32, device=dev) for s in self._tap_shapes(B, H, W)]
-                feat_ptrs = (C.c_void_p * len(taps))(*[t.data_ptr() for t in taps])
-            _lib.check(L.tedm_unet_forward(
-                handle, xin.data_ptr(), tin.data_ptr() if tin is not None else None, B, H, W,
-                eps.data_ptr() if eps is not None else None, feat_ptrs, self._workspace.data_ptr(),
-                self._workspace.numel(), stream, flags), 'tedm_unet_forward')
+            nsplit = min(self.streams, B // max(1, self.stream_min_batch // 2)) if (self.streams > 1 and B >= self.stream_min_batch and not trace) else 1
+
+            def launch(b0: int, b1: int, ws_holder, st_ptr: int):
+                """enqueue images [b0, b1) on stream st_ptr with the workspace kept in ws_holder[0]"""
+                nb = b1 - b0
+                need = L.tedm_unet_workspace_bytes(handle, nb, H, W, flags)
+                if need == 0:
+                    _lib.check(-1, f'workspace sizing for input {(nb,) + tuple(x.shape[1:])}')
+                ws = ws_holder[0]
+                if ws is None or ws.numel() < need or ws.device != dev:
+                    ws_holder[0] = None
+                    ws = ws_holder[0] = torch.empty(need, dtype=torch.uint8, device=dev)
+                fp = None
+                if taps is not None:
+                    fp = (C.c_void_p * len(taps))(*[t[b0:b1].data_ptr() for t in taps])
+                _lib.check(L.tedm_unet_forward(
+                    handle, xin[b0:b1].data_ptr(), tin[b0:b1].data_ptr() if tin is not None else None, nb, H, W,
+                    eps[b0:b1].data_ptr() if eps is not None else None, fp, ws.data_ptr(), ws.numel(), st_ptr, flags), 'tedm_unet_forward')
+
+            if nsplit <= 1:
+                holder = [self._workspace]
+                launch(0, B, holder, stream)
+                self._workspace = holder[0]
+            else:
+                # sub-batches on side streams: fork from / join into the caller's stream, so every tensor involved is ordered
+                # on the caller's stream before the fork and after the join (no record_stream bookkeeping needed)
+                cur = torch.cuda.current_stream(dev)
+                while len(self._side) < nsplit:
+                    self._side.append((torch.cuda.Stream(dev), [None]))
+                if self._side[0][0].device != dev:
+                    self._side = [(torch.cuda.Stream(dev), [None]) for _ in range(nsplit)]
+                cuts = [B * i // nsplit for i in range(nsplit + 1)]
+                for i in range(nsplit):
+                    side, holder = self._side[i]
+                    side.wait_stream(cur)
+                    launch(cuts[i], cuts[i + 1], holder, side.cuda_stream)
+                for i in range(nsplit):
+                    cur.wait_stream(self._side[i][0])
             if trace:
                 self.last_trace = self._read_trace()
             if taps is not None:

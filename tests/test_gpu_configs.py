@@ -226,3 +226,27 @@ def test_stem_and_bottleneck_attention_fp16_range(dev):
           f'init_conv rel-L2 {rel(m.last_trace["init_conv"], trb["init_conv"]):.2e}')
     assert e_small < 1e-5
     assert bool(torch.isfinite(big).all())
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'f16f4'])
+def test_sub_batches_on_two_streams_are_bit_identical(dev, prec):
+    """Unet.streams = 2: the batch runs as two sub-batches on two side HIP streams (fork / join on the caller's stream); eps and
+    the hooked decoder taps must equal the single-stream result bit for bit, repeatedly (no race between the two workspaces)."""
+    from tedm_amd import Unet, load_synth_weights
+    m = Unet(64, precision=prec)
+    load_synth_weights(m, seed=0)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(18, 1, 64, 64, generator=g).to(dev)
+    t = torch.randint(0, 1000, (18,), generator=g).to(dev)
+    with torch.no_grad():
+        e1, taps1 = m.native_forward(x, t, want_taps=True)
+        m.streams = 2
+        for _ in range(3):
+            e2, taps2 = m.native_forward(x, t, want_taps=True)
+            assert torch.equal(e1, e2) and all(torch.equal(a, b) for a, b in zip(taps1, taps2))
+        m.streams = 3
+        e3, _ = m.native_forward(x[:17], t[:17])
+        assert torch.equal(e3, e1[:17])
+        small, _ = m.native_forward(x[:4], t[:4])               # below stream_min_batch: single stream
+        assert torch.equal(small, e1[:4])

@@ -52,16 +52,28 @@ static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_
 
 struct Shape { const char* name; int C1, C2, Cout, S, gn; int k = 3; };
 
+// Every variant is checked on its own: launch configuration against the device limits BEFORE the launch, a full device
+// synchronisation + error check AFTER the first launch (a faulting variant is named instead of taking the process down with an
+// anonymous abort -- the round-2 record gpurun_out/lab8.txt ends in "dumped core" after an uncommitted variant set), events destroyed.
+static const char* g_label = "";
 template <typename K>
 static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int grid, int iters) {
+    if (threads < 64 || threads > 1024 || lds > 160 * 1024 || grid < 1 || !a.x1 || !a.out || !a.wpk) {
+        printf("variant '%s': bad launch configuration (threads %d, lds %zu, grid %d)\n", g_label, threads, lds, grid);
+        exit(2);
+    }
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
+    hipError_t err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err != hipSuccess) { printf("variant '%s' failed on its first launch: %s\n", g_label, hipGetErrorString(err)); fflush(stdout); exit(3); }
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     return ms / iters;
 }
 
@@ -75,6 +87,7 @@ static float time_kernel(K kern, const ConvArgs& a, int threads, size_t lds, int
         b.tiles_y = (b.Ho + TR - 1) / TR; b.tiles_x = (b.Wo + 31) / 32;                                              \
         b.ny = ((b.Cout + 31) / 32 + WN - 1) / WN; b.tpw = TPW; b.xcd_order = 1;                                     \
         const int grid = ((b.B * b.tiles_x * b.tiles_y + TPW - 1) / TPW) * b.ny;                                                  \
+        g_label = LABEL;                                                                                             \
         const float ms = time_kernel(NS::conv_igemm_kernel<3, 3, 1, 1, 0, WM, WN, MT, 2, 2, PRO, LAB_PREC>, b, WM * WN * 64, \
                                      (size_t)G::LDS, grid, iters);                                                   \
         res.push_back({LABEL, ms});                                                                                  \
@@ -118,7 +131,9 @@ int main(int argc, char** argv) {
         const int T = sh.k * sh.k;
         CK(hipMalloc(&w, (size_t)sh.Cout * Cin * 9 * 4)); CK(hipMalloc(&bias, sh.Cout * 4));
         CK(hipMalloc(&ga, (size_t)B * Cin * 4)); CK(hipMalloc(&gb, (size_t)B * Cin * 4));
-        CK(hipMalloc(&stats, (size_t)B * 4096 * sh.Cout * 2 * 4));
+        // statistics slab: entries = tiles per image * wave rows; the smallest tile here has 4 rows x 32 columns, WM <= 2
+        const size_t stat_entries = (size_t)((sh.S + 3) / 4) * ((sh.S + 31) / 32) * 2;
+        CK(hipMalloc(&stats, (size_t)B * stat_entries * sh.Cout * 2 * 4));
         CK(hipMalloc(&wpk, conv_packed_bytes_lab(sh.Cout, Cin, 9)));
         {   // random fill on the host (normal-ish via sum of uniforms)
             std::vector<float> h(std::max({n1, n2, (size_t)sh.Cout * Cin * 9}));
@@ -139,7 +154,7 @@ int main(int argc, char** argv) {
         std::vector<std::vector<Res>> all;
         for (int r = 0; r < rounds; ++r) {
             std::vector<Res> res;
-            if (sh.k == 1) { break; }
+            if (sh.k == 1) { if (r == 0) printf("%-14s 1x1 shape: no variant set enabled in this build (RUN1), skipped\n", sh.name); break; }
 #define ALLV(WM, WN, MT, PRO, TPW, NAME)                                                          \
     RUNT(v0, WM, WN, MT, PRO, TPW, NAME " product");                                              \
     RUNT(a1, WM, WN, MT, PRO, TPW, NAME " no staging");                                           \
@@ -156,6 +171,8 @@ int main(int argc, char** argv) {
             }
             all.push_back(res);
         }
+        for (auto& r : all)
+            if (r.size() != all[0].size()) { printf("%s: rounds produced different variant counts\n", sh.name); return 4; }
         for (size_t i = 0; !all.empty() && i < all[0].size(); ++i) {
             std::vector<float> t;
             for (auto& r : all) t.push_back(r[i].ms);
