@@ -237,7 +237,8 @@ def main() -> None:
                     help="arithmetic mode of the MFMA contractions; default: f16f4 (the library's opt-in fast inference mode; the module default is bf16x3), bf16x3 for --mode train")
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', '--no-extras', dest='no_cpu_baseline', action='store_true',
+                    help='skip the legs outside the timed region (CPU baseline + eps check, two-stream pass): what the rocprofv3 runs use')
     ap.add_argument('--streams', type=int, default=1, help='inference: sub-batches on this many HIP streams (Unet.streams; bit-identical results)')
     ap.add_argument('--buckets', type=int, default=4, help='--mode train: gradient all-reduce buckets launched under the backward (1 = one all-reduce after it)')
     ap.add_argument('--breakdown', action='store_true', help='extra pass: HIP-event time of every kernel -> stderr')
@@ -335,6 +336,22 @@ def main() -> None:
         conv_prof = _lib.profile_entries()
         elapsed = dp.max_over_ranks(dist, elapsed, dev)
 
+        # outside the timed region: the same K steps with the batch cut into two sub-batches on two side HIP streams
+        # (Unet.streams = 2, bit-identical results; kernel tails / launch gaps of one sub-batch are filled by the other).  Reported
+        # NEXT to the headline number, which stays single-stream so that per-kernel durations are those of a kernel that owns the chip.
+        multi = None
+        if args.streams == 1 and args.mode == 'denoise' and B >= 2 * 8 and not args.no_cpu_baseline:   # --no-extras runs (profiling) time ONLY the K steps
+            dm.model.streams = 2
+            for _ in range(2):
+                step()
+            sync_all()
+            m0 = time.perf_counter()
+            for _ in range(K):
+                step()
+            sync_all()
+            multi = dp.max_over_ranks(dist, time.perf_counter() - m0, dev)
+            dm.model.streams = 1
+
         breakdown = None
         if args.breakdown and rank == 0:
             L.tedm_profile_reset()
@@ -367,6 +384,9 @@ def main() -> None:
                    'parallelism': f'dp{world} (batch sharded, no data-path collective)', 'hip_streams_per_gpu': args.streams},
     }
 
+    if multi is not None:
+        out['two_streams'] = {'value': round(world * B * K / multi, 2), 'unit': 'img/s', 'ms_per_step': round(1e3 * multi / K, 4),
+                              'note': 'same K steps, batch as two sub-batches on two HIP streams (Unet.streams=2, bit-identical); outside the timed region'}
     if rank == 0:
         # ---- roofline of the dominant kernel, from HIP events recorded on the launch stream -------
         conv_prof.sort(key=lambda e: -e[2])

@@ -11,6 +11,7 @@ python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 > profi
 python bench.py --mode train --prec f16f4 --steps 10 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_train_f16f4.json
 python bench.py --mode extract --steps 5 --warmup 2 2>/dev/null | tail -1 > profiles/${tag}_bench_extract.json
 python bench.py --mode tedm --batch 16 --steps 5 --warmup 2 2>/dev/null | tail -1 > profiles/${tag}_bench_tedm.json
+python bench.py --streams 2 --no-extras 2>/dev/null | tail -1 > profiles/${tag}_bench_two_streams.json
 python bench.py --mode sample --batch 4 --steps 50 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_sample.json
 python bench.py --no-cpu-baseline --breakdown 2> profiles/${tag}_bench_hip_event_breakdown.txt > /dev/null
 # the profiled program comes directly after `--` (no env/bash hop), counters in their own passes
