@@ -200,6 +200,12 @@ int tedm_conv1x1_wgrad_nhwc(const float* dy, const float* x, int B, int H, int W
 /* out (B,S,S,C) = bias + sum_i nearest_upsample(z_i (B,h_i,w_i,C));  n <= 8 inputs. */
 int tedm_upsample_sum_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C,
                            const float* bias, float* out, void* stream);
+/* Inference-mode tail of the classifier in one pass (models/datasetDM_model.py:59-64 with eval-mode BatchNorm folded into the
+ * following conv by the caller): logits (B,S,S) = b3 + w3 . relu(b2 + W2 relu(b1 + sum_i nearest_upsample(z_i))), W2 given
+ * TRANSPOSED as w2t [C1][32] (C1 % 32 == 0, second width fixed at the reference's 32).  Neither the C1-channel nor the
+ * 32-channel tensor reaches HBM.  All pointers device; b3: 1 float. */
+int tedm_head_tail_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1,
+                        const float* w2t, const float* b2, const float* w3, const float* b3, float* logits, void* stream);
 /* adjoint of one nearest upsample by `factor`: out (B,h,w,C) = block sums of g (B,h*factor,w*factor,C). */
 int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, float* out, void* stream);
 

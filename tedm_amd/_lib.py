@@ -64,6 +64,7 @@ _SIGNATURES = {
     'tedm_conv1x1_wgrad_nhwc': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_size_t, _P]),
     'tedm_upsample_sum_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'tedm_pool_sum_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'tedm_head_tail_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     'tedm_unet_trace_count': (C.c_int, [_P]),
     'tedm_unet_trace_name': (C.c_char_p, [_P, C.c_int]),
     'tedm_unet_trace_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

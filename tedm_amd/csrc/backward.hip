@@ -48,6 +48,58 @@ __global__ void upsample_sum_kernel(UpSumArgs a, const float* __restrict__ bias,
         *(float4*)(out + (size_t)i * 4) = s;
     }
 }
+// Inference-mode tail of the pixel classifier in ONE pass (models/datasetDM_model.py:57-64 after the first conv; eval-mode
+// BatchNorm folded into the following conv by the host):
+//     h1 = b1 + sum_i nearest_up(z_i)                (the 128-channel tensor is never written)
+//     u  = b2' + W2' relu(h1)        (128 -> 32)      logit = b3' + w3' . relu(u)        (32 -> 1)
+// 256 pixels per block; per 32-channel chunk the block builds relu(h1) in LDS with coalesced loads (8 threads per pixel), then
+// every thread owns one pixel and accumulates its 32 outputs with the (wave-uniform, scalar-loaded) weights.
+constexpr int HT_PIX = 256, HT_LD = 33;
+__global__ __launch_bounds__(256) void head_tail_kernel(UpSumArgs a, const float* __restrict__ b1, const float* __restrict__ w2t /*[C1][32]*/,
+                                                        const float* __restrict__ b2, const float* __restrict__ w3,
+                                                        const float* __restrict__ b3, float* __restrict__ logits, long long P, int S, int C1) {
+    __shared__ float sa[HT_PIX * HT_LD];
+    const int tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * HT_PIX;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = b2[j];
+    for (int cb = 0; cb < C1; cb += 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                           // 2048 float4 of the chunk, 8 per thread
+            const int f = tid + 256 * k, px = f >> 3, c4 = (f & 7) * 4;
+            const long long p = p0 + px;
+            float4 sm = *(const float4*)(b1 + cb + c4);
+            if (p < P) {
+                const int x = (int)(p % S);
+                const long long r = p / S;
+                const int y = (int)(r % S), n = (int)(r / S);
+                for (int i = 0; i < a.n; ++i) {
+                    const int sy = (int)((long long)y * a.h[i] / S), sx = (int)((long long)x * a.w[i] / S);   // F.interpolate 'nearest'
+                    const float4 v = *(const float4*)(a.z[i] + (((size_t)n * a.h[i] + sy) * a.w[i] + sx) * C1 + cb + c4);
+                    sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                }
+            }
+            float* d = sa + px * HT_LD + c4;
+            d[0] = fmaxf(sm.x, 0.f); d[1] = fmaxf(sm.y, 0.f); d[2] = fmaxf(sm.z, 0.f); d[3] = fmaxf(sm.w, 0.f);
+        }
+        __syncthreads();
+        const float* row = sa + tid * HT_LD;
+#pragma unroll 4
+        for (int c = 0; c < 32; ++c) {
+            const float av = row[c];
+            const float* wr = w2t + (size_t)(cb + c) * 32;      // uniform address: scalar loads
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = fmaf(wr[j], av, acc[j]);
+        }
+        __syncthreads();
+    }
+    float lg = b3[0];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lg = fmaf(w3[j], fmaxf(acc[j], 0.f), lg);
+    if (p0 + tid < P) logits[p0 + tid] = lg;
+}
+
 // its adjoint: out[n][y][x][:] = sum over the f x f block of g that nearest-upsampling maps to (y,x)   (S = f*h)
 __global__ void pool_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int h, int w, int f, int C, long long total4) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
@@ -849,6 +901,16 @@ int op_upsample_sum(const float* const* z, const int* h, const int* w, int n, in
     long long blocks = (total4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(upsample_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, bias, out, B, S, C, total4);
+    return LAUNCH_OK();
+}
+int op_head_tail(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1, const float* w2t,
+                 const float* b2, const float* w3, const float* b3, float* logits, hipStream_t st) {
+    if (n < 1 || n > 8 || C1 % 32 || C1 < 32) return TEDM_EINVAL;
+    UpSumArgs a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) { a.z[k] = z[k]; a.h[k] = h[k]; a.w[k] = w[k]; }
+    const long long P = (long long)B * S * S;
+    hipLaunchKernelGGL(head_tail_kernel, dim3((unsigned)((P + HT_PIX - 1) / HT_PIX)), dim3(256), 0, st, a, b1, w2t, b2, w3, b3, logits, P, S, C1);
     return LAUNCH_OK();
 }
 int op_pool_sum(const float* g, float* out, int B, int h, int w, int f, int C, hipStream_t st) {

@@ -75,6 +75,9 @@ int wgrad_set_tuning(const char* key, int v);
 int wgrad_mfma_set_tuning(const char* key, int v);
 
 // backward.hip
+// eval-mode classifier tail fused with the up-sampling sum: z_i (B,h_i,w_i,C1) -> logits (B,S,S); w2t [C1][32], BatchNorm folded by the host
+int op_head_tail(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1, const float* w2t,
+                 const float* b2, const float* w3, const float* b3, float* logits, hipStream_t st);
 int op_upsample_sum(const float* const* z, const int* h, const int* w, int n, int B, int S, int C, const float* bias, float* out,
                     hipStream_t st);
 int op_pool_sum(const float* g, float* out, int B, int h, int w, int f, int C, hipStream_t st);

@@ -1050,6 +1050,15 @@ int tedm_upsample_sum_nhwc(const float* const* z, const int* h, const int* w, in
     return rc == TEDM_OK ? rc : fail(rc, "upsample_sum failed (%d)", rc);
 }
 
+int tedm_head_tail_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1, const float* w2t,
+                        const float* b2, const float* w3, const float* b3, float* logits, void* stream) {
+    g_err[0] = 0;
+    if (!z || !h || !w || !b1 || !w2t || !b2 || !w3 || !b3 || !logits) return fail(TEDM_EINVAL, "null argument");
+    if ((long long)B * S * S >= (1ll << 31)) return fail(TEDM_EINVAL, "B*S*S too large");
+    const int rc = op_head_tail(z, h, w, n, B, S, C1, b1, w2t, b2, w3, b3, logits, (hipStream_t)stream);
+    return rc == TEDM_OK ? rc : fail(rc, "head_tail: 1..8 taps, C1 a multiple of 32 (got n = %d, C1 = %d)", n, C1);
+}
+
 int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, float* out, void* stream) {
     g_err[0] = 0;
     if (!g || !out) return fail(TEDM_EINVAL, "null argument");

@@ -41,6 +41,7 @@ class DatasetDM(nn.Module):
         feat_ch = sum(s[3] for s in self.diffusion_model.model._tap_shapes(1, 8, 8))   # 960 for the default UNet
         self.feature_channels = feat_ch
         self.fused_head = bool(getattr(args, 'fused_head', True))
+        self.fused_tail = bool(getattr(args, 'fused_tail', True))     # eval + no_grad: the rest of the head as one kernel (head.fused_head_eval)
         # TEDM (trainers/train_datasetDM.py:30-42): ONE classifier shared by all timesteps.  The reference swaps it in after
         # construction; both routes work here (`args.shared_weights_over_timesteps`, config.py, or assigning
         # `model.classifier = nn.Sequential(Rearrange(...), nn.Conv2d(960, 128, 1), ...)` later).
@@ -167,10 +168,14 @@ class DatasetDM(nn.Module):
         layout = self.head_layout() if self.fused_head else None
         if layout is None:
             return self.classifier(self.extract_features(x, noise=noise).to(x.device))
-        from .head import fused_first_layer
+        from .head import eval_tail_supported, fused_first_layer, fused_head_eval
         kind, ci = layout
         unet = self.diffusion_model.model                       # the head trains at the UNet's training precision
         prec = unet.train_precision if (torch.is_grad_enabled() and self.training) else unet.precision
         taps = [self._taps_steps_in_batch(x, noise)] if kind == 'shared' else self._taps_per_step(x, noise)
-        h1 = fused_first_layer(self.classifier[ci], taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
+        conv, tail = self.classifier[ci], list(self.classifier[ci + 1:])
+        if self.fused_tail and not torch.is_grad_enabled() and eval_tail_supported(tail, conv.out_channels):
+            # inference: up-sampling sum, ReLU, both folded BatchNorms and the 128 -> 32 -> 1 layers in ONE kernel after the projections
+            return fused_head_eval(conv, tail, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
+        h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
         return self.classifier[ci + 1:](h1)

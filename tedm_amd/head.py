@@ -28,6 +28,40 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+def project_taps(W1: Tensor, prec: int, n_taps: int, taps: Sequence[Tensor]) -> List[Tensor]:
+    """z_i = sum_t tedm_conv1x1_nhwc(tap_{t,i}, W1[:, slice(t, i)]) at every tap's native resolution (accumulated over the
+    timesteps through the kernel's epilogue addend).  taps: flat [t0: tap0..tap{n-1}, t1: ...] NHWC fp32; returns n_taps tensors
+    (B, h_i, w_i, Cout)."""
+    L = _lib.lib()
+    dev = W1.device
+    Cout = W1.shape[0]
+    T = len(taps) // n_taps
+    assert T * n_taps == len(taps) and T >= 1
+    B = taps[0].shape[0]
+    w2d = W1.detach().reshape(Cout, -1).float()
+    assert w2d.shape[1] == sum(t.shape[3] for t in taps), 'classifier[0].in_channels does not match the taps'
+    st = _stream(dev)
+    z: List[Tensor] = []
+    off = 0
+    for k, tap in enumerate(taps):
+        i = k % n_taps
+        assert tap.is_contiguous() and tap.dtype == torch.float32 and tap.shape[0] == B
+        _, h, w, Ci = tap.shape
+        nbytes = L.tedm_conv1x1_packed_bytes(Cout, Ci)
+        if nbytes == 0:
+            raise _lib.TedmError(f'fused head needs Cout % 16 == 0 and tap channels % 32 == 0 (got {Cout}, {Ci})')
+        wslice = w2d[:, off:off + Ci].contiguous()          # stream-ordered allocations: safe to drop after the enqueue
+        wpk = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.tedm_conv1x1_pack(wslice.data_ptr(), Cout, Ci, wpk.data_ptr(), prec, st), 'tedm_conv1x1_pack')
+        if k < n_taps:
+            z.append(torch.empty(B, h, w, Cout, dtype=torch.float32, device=dev))
+        _lib.check(L.tedm_conv1x1_nhwc(tap.data_ptr(), B, h, w, Ci, wpk.data_ptr(), Cout, None,
+                                       z[i].data_ptr() if k >= n_taps else None, z[i].data_ptr(), prec, st),
+                   'tedm_conv1x1_nhwc')
+        off += Ci
+    return z
+
+
 class FusedFirstLayer(torch.autograd.Function):
     """h1 = Conv2d(960*T, Cout, 1)(cat_t cat_i up(tap_{t,i}))  without the concat.
 
@@ -40,33 +74,10 @@ class FusedFirstLayer(torch.autograd.Function):
         L = _lib.lib()
         dev = W1.device
         Cout = W1.shape[0]
-        T = len(taps) // n_taps
-        assert T * n_taps == len(taps) and T >= 1
         B = taps[0].shape[0]
-        w2d = W1.detach().reshape(Cout, -1).float()
-        assert w2d.shape[1] == sum(t.shape[3] for t in taps), 'classifier[0].in_channels does not match the taps'
         with torch.cuda.device(dev):
             st = _stream(dev)
-            z: List[Tensor] = []
-            off = 0
-            keep = []                                   # packed weight buffers must outlive the enqueued kernels
-            for k, tap in enumerate(taps):
-                i = k % n_taps
-                assert tap.is_contiguous() and tap.dtype == torch.float32 and tap.shape[0] == B
-                _, h, w, Ci = tap.shape
-                nbytes = L.tedm_conv1x1_packed_bytes(Cout, Ci)
-                if nbytes == 0:
-                    raise _lib.TedmError(f'fused head needs Cout % 16 == 0 and tap channels % 32 == 0 (got {Cout}, {Ci})')
-                wslice = w2d[:, off:off + Ci].contiguous()
-                wpk = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                keep += [wslice, wpk]
-                _lib.check(L.tedm_conv1x1_pack(wslice.data_ptr(), Cout, Ci, wpk.data_ptr(), prec, st), 'tedm_conv1x1_pack')
-                if k < n_taps:
-                    z.append(torch.empty(B, h, w, Cout, dtype=torch.float32, device=dev))
-                _lib.check(L.tedm_conv1x1_nhwc(tap.data_ptr(), B, h, w, Ci, wpk.data_ptr(), Cout, None,
-                                               z[i].data_ptr() if k >= n_taps else None, z[i].data_ptr(), prec, st),
-                           'tedm_conv1x1_nhwc')
-                off += Ci
+            z = project_taps(W1, prec, n_taps, taps)
             out = torch.empty(B, S, S, Cout, dtype=torch.float32, device=dev)
             zp = (C.c_void_p * n_taps)(*[t.data_ptr() for t in z])
             hh = (C.c_int * n_taps)(*[t.shape[1] for t in z])
@@ -116,9 +127,69 @@ class FusedFirstLayer(torch.autograd.Function):
 
 def fused_first_layer(conv: torch.nn.Conv2d, taps_by_step: Sequence[Sequence[Tensor]], S: int, prec: int = 0) -> Tensor:
     """taps_by_step[t][i]: NCHW-shaped views (B, C_i, h_i, w_i) of NHWC buffers, as Unet.native_forward returns them."""
+    return FusedFirstLayer.apply(conv.weight, conv.bias, S, prec, len(taps_by_step[0]), *_flat_nhwc(taps_by_step))
+
+
+def _flat_nhwc(taps_by_step: Sequence[Sequence[Tensor]]) -> List[Tensor]:
     flat = []
     for taps in taps_by_step:
         for tp in taps:
             nhwc = tp.permute(0, 2, 3, 1)
             flat.append(nhwc if nhwc.is_contiguous() else nhwc.contiguous())
-    return FusedFirstLayer.apply(conv.weight, conv.bias, S, prec, len(taps_by_step[0]), *flat)
+    return flat
+
+
+def eval_tail_supported(tail: Sequence[torch.nn.Module], c1: int) -> bool:
+    """True when `tail` (the classifier behind its first conv) is exactly the reference's ReLU, BatchNorm2d(c1), Conv2d(c1, 32, 1),
+    ReLU, BatchNorm2d(32), Conv2d(32, 1, 1) (models/datasetDM_model.py:59-64) in eval mode: then it folds into one kernel."""
+    nn = torch.nn
+    if len(tail) != 6 or c1 % 32:
+        return False
+    r1, bn1, c2, r2, bn2, c3 = tail
+    ok = (isinstance(r1, nn.ReLU) and isinstance(r2, nn.ReLU) and isinstance(bn1, nn.BatchNorm2d) and isinstance(bn2, nn.BatchNorm2d)
+          and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d))
+    if not ok:
+        return False
+    return (bn1.num_features == c1 and bn2.num_features == 32 and not bn1.training and not bn2.training
+            and bn1.running_mean is not None and bn2.running_mean is not None
+            and c2.kernel_size == (1, 1) and c2.in_channels == c1 and c2.out_channels == 32 and c2.groups == 1
+            and c3.kernel_size == (1, 1) and c3.in_channels == 32 and c3.out_channels == 1)
+
+
+@torch.no_grad()
+def fused_head_eval(conv: torch.nn.Conv2d, tail: Sequence[torch.nn.Module], taps_by_step: Sequence[Sequence[Tensor]], S: int,
+                    prec: int = 0) -> Tensor:
+    """Inference: the whole classifier without its two wide intermediates.  First layer at the taps' native resolution
+    (`project_taps`), then ONE kernel (`tedm_head_tail_nhwc`) that up-samples and sums the projections, applies ReLU, the
+    128 -> 32 and 32 -> 1 layers with both eval-mode BatchNorms folded into the following conv.  Returns logits (B, 1, S, S)."""
+    L = _lib.lib()
+    _, bn1, c2, _, bn2, c3 = tail
+    dev = conv.weight.device
+    flat = _flat_nhwc(taps_by_step)
+    n_taps = len(taps_by_step[0])
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        z = project_taps(conv.weight, prec, n_taps, flat)
+        c1 = conv.out_channels
+
+        def fold(bn):
+            sc = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps) if bn.affine else torch.rsqrt(bn.running_var.float() + bn.eps)
+            sh = (bn.bias.float() if bn.affine else 0.0) - bn.running_mean.float() * sc
+            return sc, sh
+        s1, t1 = fold(bn1)
+        s2, t2 = fold(bn2)
+        w2 = c2.weight.float().reshape(32, c1)
+        w2t = (w2 * s1[None, :]).t().contiguous()                                    # [C1][32]
+        b2 = ((c2.bias.float() if c2.bias is not None else 0.0) + w2 @ t1).contiguous()
+        w3 = c3.weight.float().reshape(32)
+        w3f = (w3 * s2).contiguous()
+        b3 = ((c3.bias.float() if c3.bias is not None else torch.zeros(1, device=dev)) + (w3 * t2).sum()).reshape(1).contiguous()
+        b1 = (conv.bias.float() if conv.bias is not None else torch.zeros(c1, device=dev)).contiguous()
+        B = z[0].shape[0]
+        logits = torch.empty(B, 1, S, S, dtype=torch.float32, device=dev)
+        zp = (C.c_void_p * n_taps)(*[t.data_ptr() for t in z])
+        hh = (C.c_int * n_taps)(*[t.shape[1] for t in z])
+        ww = (C.c_int * n_taps)(*[t.shape[2] for t in z])
+        _lib.check(L.tedm_head_tail_nhwc(zp, hh, ww, n_taps, B, S, c1, b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), w3f.data_ptr(),
+                                         b3.data_ptr(), logits.data_ptr(), st), 'tedm_head_tail_nhwc')
+    return logits

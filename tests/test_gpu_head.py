@@ -37,10 +37,13 @@ def test_fused_head_logits_vs_reference_and_unfused(dev, golden_dir):
     dm.eval()
     x0, noise = torch.from_numpy(g['x0']).to(dev), torch.from_numpy(g['noise']).to(dev)
     with torch.no_grad():
-        fused = dm(x0, noise=noise)
+        fused = dm(x0, noise=noise)                          # eval + no_grad: projections + the one-kernel tail
+        dm.fused_tail = False
+        first_only = dm(x0, noise=noise)
         dm.fused_head = False
         plain = dm(x0, noise=noise)
     assert tuple(fused.shape) == tuple(g['logits'].shape)
+    assert rel(fused, first_only) < 1e-5
     assert rel(fused, plain) < 1e-4
     assert rel(fused, g['logits']) < 5e-3          # same bound as the unfused path (the head amplifies the 2e-5 tap error)
 

@@ -55,11 +55,15 @@ def test_shared_head_eval_vs_reference_golden(dev, golden_dir, prec, via_swap):
     T = len(dm.steps)
     x0, noise, y = (torch.from_numpy(g[k]).to(dev) for k in ('x0', 'noise', 'y'))
     with torch.no_grad():
-        fused = dm(x0, noise=noise)
+        fused = dm(x0, noise=noise)                          # projections + ONE tail kernel (head.fused_head_eval)
+        dm.fused_tail = False
+        first_only = dm(x0, noise=noise)                     # fused first layer, torch tail (what training runs)
+        dm.fused_tail = True
         dm.fused_head = False
         plain = dm(x0, noise=noise)
         dm.fused_head = True
     assert tuple(fused.shape) == tuple(g['logits'].shape) == (2 * T, 1, 64, 64)
+    assert rel(fused, first_only) < 1e-5                     # folded BatchNorms / fp32 VALU tail vs torch's layers
     tol = 2e-3 if prec == 'bf16x3' else 2e-2               # the random head amplifies the tap error (2e-5 / 3e-4) ~50x
     e_ref, e_plain = rel(fused, g['logits']), rel(fused, plain)
     prob, mask = tedm.ensemble(fused, T)
