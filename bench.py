@@ -123,6 +123,7 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
             'config': {'workload': f'DiffusionModel.train_step + backward + Adam, {B}x1x{S}x{S} per GPU, global batch {B * world} '
                                    f'(BASELINE configs[3])', 'final_loss': round(float(loss), 6), 'grad_allreduce_buckets': args.buckets if dist is not None else 0,
+                       'gradient_parity_vs_fp32_autograd': {'f16f4': '<= 3e-3 per tensor, 5e-4 over all parameters', 'bf16x3': '<= 1e-4 per tensor, 3e-5 overall'}.get(args.prec, 'n/a'),
                        'train_workspace_GiB': round(dm.model._train_ws.numel() / 2 ** 30, 2)}}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -234,7 +235,7 @@ def main() -> None:
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--prec', default=os.environ.get('TEDM_PREC'), choices=['bf16x3', 'bf16', 'fp16x2', 'f16f4'],
-                    help="arithmetic mode of the MFMA contractions; default: f16f4 (the library's opt-in fast inference mode; the module default is bf16x3), bf16x3 for --mode train")
+                    help="arithmetic mode of the MFMA contractions; default: f16f4 (the library's opt-in fast mode; the module default is bf16x3)")
     ap.add_argument('--mode', default='denoise', choices=['denoise', 'extract', 'train', 'tedm', 'sample'],
                     help="'extract' = BASELINE config 3: DatasetDM.extract_features, 5 timesteps (extra mode; the default headline is 'denoise')")
     ap.add_argument('--no-cpu-baseline', '--no-extras', dest='no_cpu_baseline', action='store_true',
@@ -279,8 +280,9 @@ def main() -> None:
     dm = DiffusionModel(cfg)
     load_synth_weights(dm.model, seed=0)
     dm = dm.to(dev).eval()
-    if args.prec is None:          # the benchmark opts into the fast inference arithmetic (gated by the eps check below); training: bf16x3
-        args.prec = dm.model.train_precision if args.mode == 'train' else 'f16f4'
+    if args.prec is None:          # the benchmark opts into the fast arithmetic f16f4 (inference: gated by the eps check below; training: forward
+        args.prec = 'f16f4'        # and data gradients in f16f4, weight gradients bf16x3: gradients within 3e-3 per tensor / 5e-4 overall of
+                                   # fp32 autograd, tests/test_gpu_train.py); `--prec bf16x3` is the library default (1e-4 per tensor)
     dm.model.precision = dm.model.train_precision = args.prec
     dm.model.streams = args.streams
 

@@ -4,6 +4,7 @@
 //   LayerNorm (+ residual), final 1x1 conv, per-channel norm / max finalizers, tap -> features.
 // Per-pixel reductions use wave64 xor-shuffles over the lanes that share a pixel.
 #include "common.h"
+#include <stdlib.h>
 #include "ops.h"
 #include "../../include/tedm_hip.h"
 
@@ -196,36 +197,27 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
     uint4* swf = (uint4*)(sx + ((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3));     // [k-step][cout tile][hi|lo][64 lanes] B fragments
     float* swe = (float*)(swf + (size_t)KS4 * NCB * 2 * 64);                    // [2][Cout]: 2^-e, 2^e of each output channel's weights
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
     // Conversions saturate at +-65504 instead of producing inf (hi = inf would make lo = v - inf = NaN), and every output
     // channel's weights are pre-scaled by a power of two into [1, 2) so that small weights do not fall into fp16's subnormal
     // range and lose the lo term (both exact: the scale is undone on the fp32 accumulator).  ADVICE r2.
+    // Once per WORKGROUP, which then walks several tiles: the per-channel maximum is a cooperative LDS integer max (the first
+    // version had thread co loop over its 49 weights serially: 60 us on a 180 us kernel), and the fragment build is amortised.
     fp16_saturate_on();
+    unsigned* smaxu = (unsigned*)swe;
+    if (tid < Cout) smaxu[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < Cout * Cin * 49; i += 256)
+        atomicMax(&smaxu[i / (Cin * 49)], __float_as_uint(w[i]) & 0x7fffffffu);            // |w| as an unsigned integer: order-preserving
+    __syncthreads();
     if (tid < Cout) {
-        float amax = 0.f;
-        for (int i = 0; i < Cin * 49; ++i) amax = fmaxf(amax, fabsf(w[(size_t)tid * Cin * 49 + i]));
-        int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;
-        e = amax > 0.f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
-        swe[tid] = ldexpf(1.f, -e);
+        const unsigned am = smaxu[tid];
+        int e = (int)((am >> 23) & 0xff) - 127;
+        e = am != 0u ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
+        swe[tid] = ldexpf(1.f, -e);                         // (overwrites this thread's own scratch word)
         swe[Cout + tid] = ldexpf(1.f, e);
     }
     __syncthreads();
-    const int li = lane & 31, lk = lane >> 5;
-    const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
-    int tile = blockIdx.x;
-    const int n = tile / (tiles_x * tiles_y);
-    tile -= n * tiles_x * tiles_y;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int oy0 = ty * STEM_TR, ox0 = tx * STEM_TC;
-    for (int i = tid; i < Cin * (STEM_HR + 1) * STEM_HC; i += 256) {
-        const int ci = i / ((STEM_HR + 1) * STEM_HC);
-        const int rem = i - ci * (STEM_HR + 1) * STEM_HC;
-        const int hy = rem / STEM_HC, hx = rem - hy * STEM_HC;
-        const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
-        const bool ok = hy < STEM_HR && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];          // unconditional load, clamped address
-        sx[i] = ok ? v : 0.f;
-    }
     // weight fragments: lane (cout li, half hk) of k-step (ci, s) holds w[co][ci][ky = 2 s + hk][kx = j], j < 7
     for (int f = tid; f < KS4 * NCB * 64; f += 256) {
         const int ln = f & 63, c = (f >> 6) % NCB, ks = f / (64 * NCB);
@@ -238,56 +230,75 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
         swf[((ks * NCB + c) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
         swf[((ks * NCB + c) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
     }
-    __syncthreads();
-    f32x16 acc[2][NCB];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
-    for (int ks = 0; ks < KS4; ++ks) {
-        const int ci = ks >> 2, s_ = ks & 3;
-        f16x8 bh[NCB], bl[NCB];
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            bh[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 0) * 64 + lane]);
-            bl[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 1) * 64 + lane]);
+    const int tiles_x = (W + STEM_TC - 1) / STEM_TC, tiles_y = (H + STEM_TR - 1) / STEM_TR;
+    const int ntiles = B * tiles_x * tiles_y;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int n = tl / (tiles_x * tiles_y);
+        const int trem = tl - n * tiles_x * tiles_y;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * STEM_TR, ox0 = tx * STEM_TC;
+        for (int i = tid; i < Cin * (STEM_HR + 1) * STEM_HC; i += 256) {
+            const int ci = i / ((STEM_HR + 1) * STEM_HC);
+            const int rem = i - ci * (STEM_HR + 1) * STEM_HC;
+            const int hy = rem / STEM_HC, hx = rem - hy * STEM_HC;
+            const int iy = oy0 + hy - 3, ix = ox0 + hx - 3;
+            const bool ok = hy < STEM_HR && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const float v = x[((size_t)(n * Cin + ci) * H + iyc) * W + ixc];          // unconditional load, clamped address
+            sx[i] = ok ? v : 0.f;
         }
+        __syncthreads();                                     // sx (and, the first time, swf) complete
+        f32x16 acc[2][NCB];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            // halo row of output row (2 wave + m), tap row 2 s + lk; row STEM_HR (index 14) is the zero row (tap row 7 of the last rows)
-            const float* ax = sx + (ci * (STEM_HR + 1) + 2 * wave + m + 2 * s_ + lk) * STEM_HC + li;
-            float av[8];
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int j = 0; j < 7; ++j) av[j] = ax[j];
-            av[7] = 0.f;
-            if (2 * s_ + lk >= 7) {
+            for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                for (int j = 0; j < 7; ++j) av[j] = 0.f;
-            }
-            f16x8 ah, al;
-            stem_split(av, ah, al);
+                for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+        for (int ks = 0; ks < KS4; ++ks) {
+            const int ci = ks >> 2, s_ = ks & 3;
+            f16x8 bh[NCB], bl[NCB];
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
-                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc[m][c], 0, 0, 0);
-                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc[m][c], 0, 0, 0);
-                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc[m][c], 0, 0, 0);
+                bh[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 0) * 64 + lane]);
+                bl[c] = __builtin_bit_cast(f16x8, swf[((ks * NCB + c) * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                // halo row of output row (2 wave + m), tap row 2 s + lk; row STEM_HR (index 14) is the zero row (tap row 7 of the last rows)
+                const float* ax = sx + (ci * (STEM_HR + 1) + 2 * wave + m + 2 * s_ + lk) * STEM_HC + li;
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) av[j] = ax[j];
+                av[7] = 0.f;
+                if (2 * s_ + lk >= 7) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) av[j] = 0.f;
+                }
+                f16x8 ah, al;
+                stem_split(av, ah, al);
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[c], acc[m][c], 0, 0, 0);
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[c], acc[m][c], 0, 0, 0);
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[c], acc[m][c], 0, 0, 0);
+                }
             }
         }
-    }
+        __syncthreads();                                     // every wave is done with sx before the next tile overwrites it
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int oy = oy0 + 2 * wave + m;
-        if (oy >= H) continue;
+        for (int m = 0; m < 2; ++m) {
+            const int oy = oy0 + 2 * wave + m;
+            if (oy >= H) continue;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const int co = c * 32 + li;
-            const float bs = bias[co], sc = swe[Cout + co];
+            for (int c = 0; c < NCB; ++c) {
+                const int co = c * 32 + li;
+                const float bs = bias[co], sc = swe[Cout + co];
 #pragma unroll
-            for (int s_ = 0; s_ < 16; ++s_) {
-                const int ox = ox0 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk;
-                if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = fmaf(acc[m][c][s_], sc, bs);
+                for (int s_ = 0; s_ < 16; ++s_) {
+                    const int ox = ox0 + (s_ & 3) + 8 * (s_ >> 2) + 4 * lk;
+                    if (ox < W) out[((size_t)(n * H + oy) * W + ox) * Cout + co] = fmaf(acc[m][c][s_], sc, bs);
+                }
             }
         }
     }
@@ -779,8 +790,11 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
     const int K = Cin * 49;
     if (Cin <= 2 && (Cout == 32 || Cout == 64)) {                 // fp16 hi/lo matrix-core path (the model's stem: Cin = 1)
         const size_t lds = (size_t)((Cin * (STEM_HR + 1) * STEM_HC + 3) & ~3) * 4 + (size_t)Cin * 4 * (Cout / 32) * 2 * 1024 + (size_t)2 * Cout * 4;
-        if (Cout == 32) hipLaunchKernelGGL(stem_conv_f16_kernel<1>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
-        else hipLaunchKernelGGL(stem_conv_f16_kernel<2>, dim3(B * tiles), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        // persistent workgroups: at most 8 per CU (19 KB of LDS each), every one builds the weight fragments once and walks its tiles
+        const int cap = 256 * 8;             // measured at 32x256x256: 1024 WGs 215 us, 2048 188-195, 4096 213, one tile per WG (8192) 243
+        const int nwg = B * tiles < cap ? B * tiles : cap;
+        if (Cout == 32) hipLaunchKernelGGL(stem_conv_f16_kernel<1>, dim3(nwg), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
+        else hipLaunchKernelGGL(stem_conv_f16_kernel<2>, dim3(nwg), dim3(256), lds, st, x, w, bias, out, B, Cin, H, W, Cout);
         return LAUNCH_OK();
     }
     if (K <= 128 && (Cout == 32 || Cout == 64)) {                 // exact-fp32 matrix-core path

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 python bench.py > gpurun_out/${tag}_bench.log 2>&1 && tail -1 gpurun_out/${tag}_bench.log > profiles/${tag}_bench.json
-python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_train.json
+python bench.py --mode train --prec bf16x3 --steps 10 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_train.json
 python bench.py --mode train --prec f16f4 --steps 10 --warmup 3 2>/dev/null | tail -1 > profiles/${tag}_bench_train_f16f4.json
 python bench.py --mode extract --steps 5 --warmup 2 2>/dev/null | tail -1 > profiles/${tag}_bench_extract.json
 python bench.py --mode tedm --batch 16 --steps 5 --warmup 2 2>/dev/null | tail -1 > profiles/${tag}_bench_tedm.json
