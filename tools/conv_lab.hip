@@ -46,6 +46,11 @@ namespace a7 {
 #include "conv_igemm.inc"
 }
 #undef CONV_LAB_ABL
+namespace ns {
+#define CONV_LAB_NOSCALE 1
+#include "conv_igemm.inc"
+}
+#undef CONV_LAB_NOSCALE
 
 static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -160,7 +165,8 @@ int main(int argc, char** argv) {
     RUNT(a1, WM, WN, MT, PRO, TPW, NAME " no staging");                                           \
     RUNT(a4, WM, WN, MT, PRO, TPW, NAME " no weight reloads");                                    \
     RUNT(a5, WM, WN, MT, PRO, TPW, NAME " neither");                                              \
-    RUNT(a7, WM, WN, MT, PRO, TPW, NAME " neither, no stores")
+    RUNT(a7, WM, WN, MT, PRO, TPW, NAME " neither, no stores");                                     \
+    RUNT(ns, WM, WN, MT, PRO, TPW, NAME " no scale-byte LDS read")
             if (sh.Cout < 128) {
                 if (sh.gn) { ALLV(2, 2, 4, 1, 4, "narrow"); } else { ALLV(2, 2, 4, 0, 4, "narrow"); }
             } else if (sh.Cout < 256) {
