@@ -27,17 +27,23 @@ struct TileSel { int wm, wn, mt; };
 // stride-2 convs use half the rows (the halo doubles).
 //   id 3 "wide8w"  : 2x4 waves (512 threads), 4 M-tiles -> 256 px x 128 cout
 //   id 4 "wide256" : 1x8 waves (512 threads), 4 M-tiles -> 128 px x 256 cout
+//   id 6 "narrow16": 4x2 waves (512 threads), 4 M-tiles -> 512 px x 64 cout, one workgroup per CU: a halo of 18 rows serves 16
+//                    (2x2: 10 for 8) and eight waves share every weight fragment (+3-7 % on the full-resolution 3x3 convs)
+//   id 5 "tall256" : 1x8 waves (512 threads), 8 M-tiles -> 256 px x 256 cout, one workgroup per CU (<= 256 VGPRs): every weight
+//                    fragment feeds 8 MFMAs instead of 4 and a halo of 10 rows serves 8 (+4-9 % single fp16 product, +11-15 % f16f4
+//                    on the 256- and 512-channel 3x3 convs: profiles/r03_conv_lab_tiles.txt)
 int g_tile_wide = 3;      // tile id used when Cout >= 128 (tedm_set_tuning("conv_tile_wide", v)); 2x4 waves: two wave rows share
                           // every weight fragment (half the L2 weight traffic per FLOP of the 1x4 tile)
-int g_tile_narrow = 1;
+int g_tile_narrow = 6;
 // g_tile_narrow: tile id used when Cout < 128 (tedm_set_tuning("conv_tile_narrow", v))
 
-int g_tile_wide256 = 4;   // tile id used when Cout >= 256 (tedm_set_tuning("conv_tile_wide256", v)): 1x8 waves = 256 couts per
+int g_tile_wide256 = 5;   // tile id used when Cout >= 256 (tedm_set_tuning("conv_tile_wide256", v)): 1x8 waves = 256 couts per
                           // workgroup: every staged input pixel feeds twice the MFMAs of the 128-cout tiles (+5-9 %, conv_lab)
 
 // 1x1 convolutions with 128 <= Cout < 256 (HBM-bound res_conv / to_out) run 12 % faster on the 1x4-wave tile (conv_lab)
 inline int select_tile_id(int Cout, int KH = 3) {
-    return Cout >= 256 ? g_tile_wide256 : (Cout >= 128 ? (KH == 1 && g_tile_wide == 3 ? 2 : g_tile_wide) : g_tile_narrow);
+    // (1x1 convs keep the 4-row tile: single LDS buffer, several small workgroups per CU)
+    return Cout >= 256 ? (KH == 1 && g_tile_wide256 == 5 ? 4 : g_tile_wide256) : (Cout >= 128 ? (KH == 1 && g_tile_wide == 3 ? 2 : g_tile_wide) : (KH == 1 && g_tile_narrow == 6 ? 1 : g_tile_narrow));
 }
 inline TileSel tile_geom(int id, int stride) {
     TileSel t;
@@ -47,6 +53,8 @@ inline TileSel tile_geom(int id, int stride) {
         case 2: t = TileSel{1, 4, 4}; break;
         case 3: t = TileSel{2, 4, 4}; break;
         case 4: t = TileSel{1, 8, 4}; break;
+        case 5: t = TileSel{1, 8, 8}; break;
+        case 6: t = TileSel{4, 2, 4}; break;
         default: t = TileSel{2, 4, 4}; break;
     }
     if (stride == 2) t.mt = t.mt > 1 ? t.mt / 2 : t.mt;
@@ -56,15 +64,22 @@ inline TileSel tile_geom(int id, int stride) {
 int g_conv_small_grid = 1;   // tedm_set_tuning("conv_small_grid", 0|1)
 
 // Small batches (the sampler, single images): when the default tile would launch fewer workgroups than the chip has CUs, halve the
-// output channels per workgroup (same rows per tile, hence the same statistics slab and -- every output accumulates its taps and
-// channel chunks in the same order whatever shares its workgroup -- the same bits).
-inline int effective_tile(const ConvArgs& a, int KH, int stride, int ups) {
-    int id = select_tile_id(a.Cout, KH);
-    if (!g_conv_small_grid) return id;
+// rows (tall256 -> wide256), then the output channels per workgroup.  The statistics slab is per 4 output rows whatever the tile
+// (conv_igemm.inc) and every output accumulates its taps and channel chunks in the same order whatever shares its workgroup, so
+// the results are the same bits.
+inline long long tile_workgroups(const ConvArgs& a, int id, int stride, int ups) {
     const TileSel t = tile_geom(id, stride);
     const int TR = t.wm * t.mt, Ho = ups == 3 ? a.H : a.Ho, Wo = ups == 3 ? a.W : a.Wo;
-    const long long wgs = (long long)a.B * ((Ho + TR - 1) / TR) * ((Wo + 31) / 32) * (ups == 3 ? 4 : 1) * (((a.Cout + 31) / 32 + t.wn - 1) / t.wn);
-    if (wgs < 256) { if (id == 4) id = 2; else if (id == 3) id = 1; }
+    return (long long)a.B * ((Ho + TR - 1) / TR) * ((Wo + 31) / 32) * (ups == 3 ? 4 : 1) * (((a.Cout + 31) / 32 + t.wn - 1) / t.wn);
+}
+inline int effective_tile(const ConvArgs& a, int KH, int stride, int ups, int pro) {
+    int id = select_tile_id(a.Cout, KH);
+    if (id == 6 && stride == 2) id = 1;                           // (the 16-row halo of a stride-2 conv does not fit the LDS)
+    if (a.out_q16 || a.add_q16 || pro == PRO_GNQ) { if (id == 5) id = 4; else if (id == 6) id = 1; }     // Q16 boundaries: instances of tiles 1-4 only
+    if (!g_conv_small_grid) return id;
+    if (id == 5 && tile_workgroups(a, id, stride, ups) < 256) id = 4;
+    if (id == 6 && tile_workgroups(a, id, stride, ups) < 256) id = 1;
+    if (tile_workgroups(a, id, stride, ups) < 256) { if (id == 4) id = 2; else if (id == 3) id = 1; }
     return id;
 }
 
@@ -72,19 +87,19 @@ inline int effective_tile(const ConvArgs& a, int KH, int stride, int ups) {
 
 int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_tile_wide") && v >= 0 && v <= 3) { g_tile_wide = v; return TEDM_OK; }
-    if (!strcmp(key, "conv_tile_wide256") && v >= 0 && v <= 4) { g_tile_wide256 = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tile_wide256") && v >= 0 && v <= 5) { g_tile_wide256 = v; return TEDM_OK; }
     if (!strcmp(key, "conv_prio") && v >= 0 && v <= 3) { g_conv_prio_mode = v; return TEDM_OK; }
     if (!strcmp(key, "conv_solo") && (v == 0 || v == 1)) { g_conv_solo = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tpw_max") && v >= 1 && v <= 64) { g_conv_tpw_max = v; return TEDM_OK; }
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_conv_xcd_order = v; return TEDM_OK; }
-    if (!strcmp(key, "conv_tile_narrow") && v >= 0 && v <= 3) { g_tile_narrow = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_tile_narrow") && ((v >= 0 && v <= 3) || v == 6)) { g_tile_narrow = v; return TEDM_OK; }
     if (!strcmp(key, "conv_small_grid") && (v == 0 || v == 1)) { g_conv_small_grid = v; return TEDM_OK; }
     return TEDM_EINVAL;
 }
 
 // Label == the rocprof kernel symbol (template argument list of conv_igemm_kernel).
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
-    const int id = effective_tile(a, KH, stride, ups);
+    const int id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
     const int qio = (a.out_q16 ? 1 : 0) | (a.add_q16 ? 2 : 0);
@@ -96,9 +111,10 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
 }
 
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {
-    const TileSel t = tile_geom(select_tile_id(Cout, KH), stride);
-    const int TR = t.wm * t.mt;
-    return ((Ho + TR - 1) / TR) * ((Wo + 31) / 32) * t.wm;
+    // one entry per group of RB output rows and tile of 32 columns, the same for every tile shape (conv_igemm.inc: RB / SG)
+    (void)KH; (void)Cout;
+    const int RB = stride == 1 ? 4 : 2;
+    return ((Ho + RB - 1) / RB) * ((Wo + 31) / 32);
 }
 
 size_t conv_packed_bytes(int Cout, int Cin, int taps) {
@@ -112,7 +128,7 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 || a.C1 % 16 || (a.x2 && a.C2 % 16)) return TEDM_EINVAL;
     if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
-    const int tile_id = effective_tile(a, KH, stride, ups);
+    const int tile_id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(tile_id, stride);
     const int TR = t.wm * t.mt;
     if (ups == 3) {                                               // parity convs: the kernel's grid is the low-resolution one

@@ -373,25 +373,39 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ film, int film_stride,
                                                           float* __restrict__ oa, float* __restrict__ ob,
                                                           float* __restrict__ mr_out /*[B][groups][2] or null*/) {
-    __shared__ double r1[256], r2[256];
+    __shared__ double r1[4], r2[4];
     const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
     const int cg = C / groups;
     double s1 = 0.0, s2 = 0.0;
-    const int total = E * cg;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int e = i / cg, c = g * cg + (i - e * cg);
-        const float2 v = *(const float2*)(slab + (((size_t)n * E + e) * C + c) * 2);
-        s1 += v.x; s2 += v.y;
+    const float* base = slab + ((size_t)n * E * C + (size_t)g * cg) * 2;
+    if ((cg & 1) == 0) {
+        // an entry's cg (sum, sumsq) pairs are cg/2 consecutive float4; four independent loads in flight per lane
+        const int q = cg >> 1, total = E * q;
+        auto ld = [&](int i) { const int e = i / q, j = i - e * q; return *(const float4*)(base + (size_t)e * C * 2 + j * 4); };
+        int i = threadIdx.x;
+        for (; i + 768 < total; i += 1024) {
+            const float4 v0 = ld(i), v1 = ld(i + 256), v2 = ld(i + 512), v3 = ld(i + 768);
+            s1 += ((double)v0.x + (double)v0.z) + ((double)v1.x + (double)v1.z) + (((double)v2.x + (double)v2.z) + ((double)v3.x + (double)v3.z));
+            s2 += ((double)v0.y + (double)v0.w) + ((double)v1.y + (double)v1.w) + (((double)v2.y + (double)v2.w) + ((double)v3.y + (double)v3.w));
+        }
+        for (; i < total; i += 256) { const float4 v = ld(i); s1 += (double)v.x + (double)v.z; s2 += (double)v.y + (double)v.w; }
+    } else {
+        const int total = E * cg;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int e = i / cg, c = i - e * cg;
+            const float2 v = *(const float2*)(base + ((size_t)e * C + c) * 2);
+            s1 += v.x; s2 += v.y;
+        }
     }
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
-        __syncthreads();
-    }
+    s1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    s2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
     const double cnt = (double)hw * cg;
-    const double mean = r1[0] / cnt;
-    double var = r2[0] / cnt - mean * mean;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float meanf = (float)mean;

@@ -15,7 +15,12 @@ SHAPES = {   # name: (k, stride, ups, C1, C2, Cout, S, gn)
     'l2_256_256_gn': (3, 1, 0, 256, 0, 256, 64, 1),
     'l3_512_512_gn': (3, 1, 0, 512, 0, 512, 32, 1),
     'l3_768_512':    (3, 1, 0, 512, 256, 512, 32, 0),
+    'l2_384_256':    (3, 1, 0, 256, 128, 256, 64, 0),
     'up_512_256':    (3, 1, 1, 512, 0, 256, 32, 0),
+    'up3_512_256':   (3, 1, 3, 512, 0, 256, 32, 0),
+    'up3_256_128':   (3, 1, 3, 256, 0, 128, 64, 0),
+    'dn_256_256':    (4, 2, 0, 256, 0, 256, 64, 0),
+    'l3_256_512':    (3, 1, 0, 256, 0, 512, 32, 0),
     'dn_64_64':      (4, 2, 0, 64, 0, 64, 256, 0),
     'res_128_64':    (1, 1, 0, 64, 64, 64, 256, 0),
 }
@@ -49,7 +54,7 @@ def main():
         if gn:
             ga = (1 + 0.1 * torch.randn(B, C1 + C2, generator=g)).to(dev); gb = (0.1 * torch.randn(B, C1 + C2, generator=g)).to(dev)
         E = L.tedm_op_conv2d_stats_entries(Cout, k, stride, So, So)
-        st = torch.zeros(B, E, Cout, 2, device=dev)
+        st = torch.zeros(B, E, Cout, 2, device=dev) if ups != 3 else None
         flops = 2.0 * B * So * So * Cout * (C1 + C2) * k * k
         byts = 4.0 * B * (S * S * (C1 + C2) + So * So * Cout)
         for prec in map(int, a.prec.split(',')):

@@ -167,6 +167,13 @@ int main(int argc, char** argv) {
     RUNT(a5, WM, WN, MT, PRO, TPW, NAME " neither");                                              \
     RUNT(a7, WM, WN, MT, PRO, TPW, NAME " neither, no stores");                                     \
     RUNT(ns, WM, WN, MT, PRO, TPW, NAME " no scale-byte LDS read")
+#ifdef LAB_TILES     // tile-shape comparison of the product kernel only (-DLAB_TILES): rows per wave 4 vs 8
+#define TILES(PRO)                                                                                                     \
+    if (sh.Cout < 128)      { RUNT(v0, 2, 2, 4, PRO, 4, "2x2 mt4 (product)"); RUNT(v0, 4, 2, 4, PRO, 2, "4x2 mt4 tpw2"); RUNT(v0, 4, 2, 4, PRO, 4, "4x2 mt4 tpw4"); }                                         \
+    else if (sh.Cout < 256) { RUNT(v0, 2, 4, 4, PRO, 1, "2x4 mt4 (product)"); RUNT(v0, 1, 4, 8, PRO, 1, "1x4 mt8"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); } \
+    else                    { RUNT(v0, 1, 8, 4, PRO, 1, "1x8 mt4 (product)"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); }
+            if (sh.gn) { TILES(1) } else { TILES(0) }
+#else
             if (sh.Cout < 128) {
                 if (sh.gn) { ALLV(2, 2, 4, 1, 4, "narrow"); } else { ALLV(2, 2, 4, 0, 4, "narrow"); }
             } else if (sh.Cout < 256) {
@@ -175,6 +182,7 @@ int main(int argc, char** argv) {
                 if (sh.gn) { RUNT(v0, 1, 8, 4, 1, 1, "1x8 mt4"); RUNT(v0, 1, 8, 8, 1, 1, "1x8 mt8"); RUNT(v0, 1, 4, 8, 1, 1, "1x4 mt8 (1 wave/SIMD)"); }
                 else       { RUNT(v0, 1, 8, 4, 0, 1, "1x8 mt4"); RUNT(v0, 1, 8, 8, 0, 1, "1x8 mt8"); RUNT(v0, 1, 4, 8, 0, 1, "1x4 mt8 (1 wave/SIMD)"); }
             }
+#endif
             all.push_back(res);
         }
         for (auto& r : all)
