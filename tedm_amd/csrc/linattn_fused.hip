@@ -552,6 +552,17 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
     };
     Raw R0, R1;
     static_assert(NC % 2 == 0, "two register sets alternate over the chunks of a tile");
+    // C = 64 (two chunks): the q weights of both chunks stay in registers for the whole workgroup and both chunks of a tile are
+    // staged in front of ONE barrier (three barriers per tile instead of four, twelve MFMAs back to back, the next tile's
+    // activations in flight for a whole tile period)
+    constexpr bool ONE = NC == 2;
+    uint4 bq1[3] = {}; unsigned bs1 = 0;
+    if (ONE) {
+        load_w(1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq1[p] = bq[p];
+        bs1 = bs;
+    }
     if (t_beg < t_end) { prefetch(t_beg, 0, R0); load_w(0); prefetch(t_beg, 1, R1); }   // all VMEM unconditional: see la_proj_kernel
     constexpr bool XPF = NTH == 1;                             // residual input of phase B fetched a whole tile early
     for (long long t = t_beg; t < t_end; ++t) {
@@ -599,8 +610,39 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
             const long long tn = wrap ? (t + 1 < t_end ? t + 1 : t) : t;       // past the last tile: an unused re-load of it
             prefetch(tn, wrap ? c + 2 - NC : c + 2, R);
         };
+        if constexpr (ONE) {
+            stage(0, 0, R0);
+            stage(1, 1, R1);
+            const long long tn = t + 1 < t_end ? t + 1 : t;    // past the last tile: an unused re-load of it
+            prefetch(tn, 0, R0);
+            prefetch(tn, 1, R1);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const char* sb = smem + c * STG;
+                const uint4* wb = c ? bq1 : bq;
+                const f16x8 b0 = __builtin_bit_cast(f16x8, wb[0]), b1 = __builtin_bit_cast(f16x8, wb[1]);
+                i32x8 b4 = {};
+                b4[0] = wb[2].x; b4[1] = wb[2].y; b4[2] = wb[2].z; b4[3] = wb[2].w;
+                const int bsv = (int)(c ? bs1 : bs);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const char* rec = sb + (mt * 32 + r) * PS;
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + h * 16));
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + 32 + h * 16));
+                    const uint4 aq = *(const uint4*)(rec + 64 + h * 16);
+                    const int as = *(const unsigned char*)(rec + 96 + h);
+                    i32x8 a4 = {};
+                    a4[0] = aq.x; a4[1] = aq.y; a4[2] = aq.z; a4[3] = aq.w;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a0, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a1, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b4, a4, acc[mt], 4, 4, 0, bsv, 0, as);
+                }
+            }
+        } else {
 #pragma unroll 1
-        for (int c = 0; c < NC; c += 2) { step(c, 0, R0); step(c + 1, 1, R1); }
+            for (int c = 0; c < NC; c += 2) { step(c, 0, R0); step(c + 1, 1, R1); }
+        }
         // softmax over d (lane-local + one exchange), o^T = ctx^T q', encoded as this head's 32-channel record
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {

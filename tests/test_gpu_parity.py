@@ -274,6 +274,60 @@ def test_conv_identity_weight_asymmetric(lib, dev):
     assert torch.equal(out4, F.conv2d(x, w2, None, padding=1))
 
 
+TILE_CASES = [
+    # k, stride, ups, C1, C2, Cout, H, W, B
+    (3, 1, 0, 64, 0, 64, 40, 72, 2),      # 64 couts: 4x2 waves (16-row tile) vs 2x2; ragged rows and columns
+    (3, 1, 0, 32, 32, 64, 21, 33, 1),     # ... concat, 21 rows: the last 16-row tile holds 5
+    (3, 1, 0, 64, 0, 256, 21, 45, 2),     # 256 couts: 1x8 waves x 8 rows vs x 4 rows; 21 rows: the last 8-row tile holds 5 (row group 2 absent)
+    (3, 1, 0, 64, 0, 512, 12, 32, 1),     # two cout groups of 256
+    (3, 1, 3, 64, 0, 256, 9, 20, 1),      # parity up-conv on the 8-row tile
+    (4, 2, 0, 64, 0, 256, 24, 64, 1),     # stride 2: 1x8 waves x 4 rows vs x 2 rows
+]
+
+
+@pytest.mark.parametrize('prec', [0, 3, 4], ids=['bf16x3', 'f16f4', 'fp16'])
+@pytest.mark.parametrize('case', TILE_CASES, ids=lambda c: 'k{}s{}u{}_{}+{}to{}_{}x{}'.format(*c[:8]))
+def test_conv_tiles_same_bits(lib, dev, case, prec):
+    """The dispatch may pick any tile shape per launch (conv_igemm.hip: 4x2-wave / 1x8-wave x 8-row tiles for large grids, the 2x2 /
+    x 4-row tiles for small ones): outputs AND the statistics slabs (one entry per 4-row group and 32-column tile whatever the
+    tile) must not differ in a single bit, with and without the GroupNorm prologue."""
+    k, stride, ups, C1, C2, Cout, H, W, B = case
+    x1 = rnd(B, C1, H, W, seed=31)
+    x2 = rnd(B, C2, H, W, seed=32) if C2 else None
+    w = rnd(Cout, C1 + C2, k, k, seed=33, scale=(1.0 / ((C1 + C2) * k * k)) ** 0.5)
+    b = rnd(Cout, seed=34, scale=0.1)
+    gn = (1 + 0.2 * rnd(B, C1 + C2, seed=35), 0.3 * rnd(B, C1 + C2, seed=36)) if (k == 3 and not ups) else None
+    xin = torch.cat((x1, x2), 1) if C2 else x1
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding={3: 1, 4: 1}[k])
+    res = {}
+    try:
+        _lib_check = lambda key, v: lib.tedm_set_tuning(key, v) == 0 or pytest.fail(f'tuning {key}={v}')
+        _lib_check(b'conv_small_grid', 0)                         # keep the chosen tile at these small sizes
+        for name, narrow, wide in (('new', 6, 5), ('old', 1, 4)):
+            _lib_check(b'conv_tile_narrow', narrow)
+            _lib_check(b'conv_tile_wide256', wide)
+            out, st = run_conv(lib, dev, x1, x2, w, b, k, stride, ups, stats_mode=0 if ups else 1, prec=prec)
+            out_m, mx = run_conv(lib, dev, x1, x2, w, b, k, stride, ups, stats_mode=0 if ups else 2, prec=prec)
+            og = run_conv(lib, dev, x1, x2, w, b, k, stride, ups, gn=gn, stats_mode=1, prec=prec) if gn is not None else None
+            res[name] = (out, st, out_m, mx, og)
+    finally:
+        lib.tedm_set_tuning(b'conv_small_grid', 1)
+        lib.tedm_set_tuning(b'conv_tile_narrow', 6)
+        lib.tedm_set_tuning(b'conv_tile_wide256', 5)
+    new, old = res['new'], res['old']
+    assert torch.isfinite(new[0]).all()
+    assert rel(new[0], ref) < {0: KERNEL_TOL, 3: 2e-3, 4: 2e-3}[prec]
+    assert torch.equal(new[0], old[0]) and torch.equal(new[2], old[2])
+    if not ups:
+        assert torch.equal(new[1], old[1]) and torch.equal(new[3], old[3])
+        assert rel(new[1][..., 1].sum(1), (new[0].double() ** 2).sum(dim=(2, 3))) < 1e-5      # every pixel counted once
+        assert torch.equal(new[3][..., 0].max(1).values, new[0].amax(dim=(2, 3)))
+    if gn is not None:
+        assert torch.equal(new[4][0], old[4][0]) and torch.equal(new[4][1], old[4][1])
+
+
 def test_conv_prologues_and_epilogues(lib, dev):
     B, Cc, H, W, Cout = 2, 64, 24, 40, 64
     x = rnd(B, Cc, H, W, seed=11)
