@@ -438,40 +438,54 @@ __global__ __launch_bounds__(256) void resblock_out_kernel(const float* __restri
     const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
     const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
-        const long long p = p0 + sub;
-        const bool ok = p < P;
-        const int n = ok ? (int)(p / hw) : 0;
-        float4 val[V];
-        float s = 0.f;
+    // U pixel groups per iteration: all loads of both groups are issued before the first SiLU (twice the bytes in flight per wave)
+    constexpr int U = V <= 2 ? 2 : 1;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw * U) {
+        float4 yy[U][V], xx[U][V], aa[U][V], bb[U][V];
+        bool ok[U];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const int c = (v * lpp + q) * 4;
-            val[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const float4 yy = *(const float4*)(y + (size_t)p * C + c);
-                const float4 aa = *(const float4*)(ga + (size_t)n * C + c);
-                const float4 bb = *(const float4*)(gb + (size_t)n * C + c);
-                const float4 xx = *(const float4*)(x + (size_t)p * C + c);
-                val[v].x = silu_f(fmaf(aa.x, yy.x, bb.x)) + xx.x;
-                val[v].y = silu_f(fmaf(aa.y, yy.y, bb.y)) + xx.y;
-                val[v].z = silu_f(fmaf(aa.z, yy.z, bb.z)) + xx.z;
-                val[v].w = silu_f(fmaf(aa.w, yy.w, bb.w)) + xx.w;
-                *(float4*)(out + (size_t)p * C + c) = val[v];
-            }
-            s += (val[v].x + val[v].y) + (val[v].z + val[v].w);
-        }
-        if (lnstats) {                                         // uniform branch
-            const float mean = group_sum(s, lpp) / (float)C;
-            float d2 = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const long long pu = p0 + u * nwaves * ppw + sub;
+            ok[u] = pu < P;
+            const long long p = ok[u] ? pu : P - 1;             // unconditional loads, clamped address
+            const int n = (int)(p / hw);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const float dx = val[v].x - mean, dy = val[v].y - mean, dz = val[v].z - mean, dw = val[v].w - mean;
-                d2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                const int c = (v * lpp + q) * 4;
+                yy[u][v] = *(const float4*)(y + (size_t)p * C + c);
+                xx[u][v] = *(const float4*)(x + (size_t)p * C + c);
+                aa[u][v] = *(const float4*)(ga + (size_t)n * C + c);
+                bb[u][v] = *(const float4*)(gb + (size_t)n * C + c);
             }
-            const float var = group_sum(d2, lpp) / (float)C;
-            const float rstd = rsqrtf(var + 1e-5f);
-            if (ok && q == 0) *(float2*)(lnstats + (size_t)p * 2) = make_float2(rstd, mean * rstd);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + u * nwaves * ppw + sub;
+            float4 val[V];
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int c = (v * lpp + q) * 4;
+                val[v].x = silu_f(fmaf(aa[u][v].x, yy[u][v].x, bb[u][v].x)) + xx[u][v].x;
+                val[v].y = silu_f(fmaf(aa[u][v].y, yy[u][v].y, bb[u][v].y)) + xx[u][v].y;
+                val[v].z = silu_f(fmaf(aa[u][v].z, yy[u][v].z, bb[u][v].z)) + xx[u][v].z;
+                val[v].w = silu_f(fmaf(aa[u][v].w, yy[u][v].w, bb[u][v].w)) + xx[u][v].w;
+                if (ok[u]) *(float4*)(out + (size_t)p * C + c) = val[v];
+                else val[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (val[v].x + val[v].y) + (val[v].z + val[v].w);
+            }
+            if (lnstats) {                                         // uniform branch
+                const float mean = group_sum(s, lpp) / (float)C;
+                float d2 = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float dx = val[v].x - mean, dy = val[v].y - mean, dz = val[v].z - mean, dw = val[v].w - mean;
+                    d2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+                const float var = group_sum(d2, lpp) / (float)C;
+                const float rstd = rsqrtf(var + 1e-5f);
+                if (ok[u] && q == 0) *(float2*)(lnstats + (size_t)p * 2) = make_float2(rstd, mean * rstd);
+            }
         }
     }
 }
