@@ -19,6 +19,7 @@
 #include "common.h"
 #include "ops.h"
 #include <type_traits>
+#include <string.h>
 #include "../../include/tedm_hip.h"
 
 namespace {
@@ -73,8 +74,12 @@ constexpr int pstride(int prec) { return prec == TEDM_PREC_F16F4 ? 112 : KS * 32
 #endif
 template <int EPI> struct LaTile { static constexpr int MT = EPI == LA_CTX ? LA_CTX_MT : 4; };   // M-tiles (32 px) per tile
 
-template <int EPI, int PREC>
+// ONE (CTX sweep, F16F4, C = 64): both 32-channel chunks of a 64-pixel tile are staged in front of ONE barrier (four LDS buffers:
+// tile parity x chunk), the k / v weights of both chunks stay in registers and the next tile's activations are in flight for a
+// whole tile period -- half the barriers per byte of the chunk-by-chunk loop.
+template <int EPI, int PREC, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
+    static_assert(!ONE || (EPI == LA_CTX && PREC == TEDM_PREC_F16F4), "ONE: the C = 64 context sweep in f16f4");
     constexpr int MT = LaTile<EPI>::MT, TP = MT * 32, NIT = MT / 2;   // TP*4 pieces / 256 threads
     constexpr bool F4 = PREC == TEDM_PREC_F16F4;
     constexpr int PSTRIDE = pstride(PREC);
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     // the sweeps were latency-bound (2.8 us per iteration at 256x256).  VMEM returns in order, so the (L2-hit) weight loads
     // of iteration it+1 are issued BEFORE prefetch(it+2): queued after it they would wait for its HBM round trip.
     struct Raw { float4 v[NIT][2]; float2 s[NIT]; bool ok[NIT]; };
-    float* gl = (float*)(smem + 2 * BUFSZ);                      // PreNorm gain [C] (LDS: 16 fewer live registers than per-set copies)
+    float* gl = (float*)(smem + (ONE ? 4 : 2) * BUFSZ);          // PreNorm gain [C] (LDS: 16 fewer live registers than per-set copies)
     for (int i = tid; i < a.C; i += 256) gl[i] = a.g[i];
     __syncthreads();
     // NB (measured on gfx950 / ROCm 7.2): with these loads inside `if (pixel valid)` blocks, lanes 48-63
@@ -219,6 +224,132 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     // Every VMEM instruction of the loop is issued UNCONDITIONALLY (past the end: a clamped, unused re-load): the waitcnt
     // pass merges the counts of all paths into a block, and one path without the younger loads turns the counted
     // vmcnt(N) in front of the staging into vmcnt(0) -- which waits for the prefetch issued one iteration ago as well.
+    // epilogue of one tile of the CTX sweep (acc[mt][0] = k, acc[mt][1] = v of the tile's pixels)
+    auto ctx_epilogue = [&](long long p0) __attribute__((always_inline)) {
+        if constexpr (EPI == LA_CTX) {
+            const bool full_tile = p0 + TP <= a.hw;
+            if (online) {
+                // running max of this lane's k channel over the workgroup's pixels; rescale what has been accumulated
+                float tmax = -INFINITY;
+                if (full_tile) {        // no per-pixel masks; v_max3 on the raw accumulators (fmaxf quiets every input first)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const float x0 = acc[mt][0][i], x1 = acc[mt][0][i + 1];
+                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(x0), "v"(x1));
+                        }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (p0 + mt * 32 + acc_row(i, h) < a.hw) tmax = fmaxf(tmax, acc[mt][0][i]);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(kmx, tmax);
+                const float f = (m_new == kmx) ? 1.f : __expf(kmx - m_new);     // kmx = -inf on the first tile -> 0 (accumulators are 0)
+                if (__any(f != 1.f)) {                          // wave-uniform: after the first tiles the running max rarely moves
+                    zsum *= f;
+#pragma unroll
+                    for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
+                }
+                kmx = m_new;
+            }
+            // ctx[d][e] += sum_pixel exp(k[pixel][d] - kmx[d]) v[pixel][e]: both accumulators (lane = channel, registers =
+            // pixels) are operands of a product over their row index as they stand (split_frag)
+            const float kl = kmx * 1.44269504088896340736f;   // exp(k - kmx) = exp2(k log2e - kmx log2e): one FMA + v_exp_f32
+            auto accum = [&](auto full) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full)::value;      // whole tile inside the image: no per-pixel masks
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    float ev[8], vv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * s_ + j;
+                        const bool ok = FULL || p0 + mt * 32 + acc_row(i, h) < a.hw;
+                        ev[j] = ok ? __builtin_amdgcn_exp2f(fmaf(acc[mt][0][i], 1.44269504088896340736f, -kl)) : 0.f;
+                        vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
+                        zsum += ev[j];
+                    }
+                    // ONE fp16 product: the fp16 roundings of e (in [0,1]) and v are independent across the hw pixels the sum
+                    // runs over, so their relative contribution to ctx shrinks like 2^-12 / sqrt(hw) -- far below the
+                    // projection's own error; the normaliser z is summed in fp32 above
+                    // (F16F4 mode only; the other modes keep the fp32-grade hi/lo product)
+                    if (F4) {
+                        f16x8 eh, vh;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { eh[j] = (_Float16)ev[j]; vh[j] = (_Float16)vv[j]; }
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, vh, cacc, 0, 0, 0);
+                    } else {
+                        f16x8 eh, el, vh, vl;
+                        split_frag(ev, eh, el);
+                        split_frag(vv, vh, vl);
+                        cacc = mfma_f16x3(eh, el, vh, vl, cacc);
+                    }
+                }
+            };
+            if (full_tile) accum(std::true_type{}); else accum(std::false_type{});
+        }
+    };
+    if constexpr (ONE) {
+        // weights of both chunks resident: chunk 0 in bq[0] / bsc, chunk 1 in bq1 / bsc1
+        uint4 bq1[NT][NPB]; unsigned bsc1[NT];
+        load_w(1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int p = 0; p < NPB; ++p) bq1[j][p] = bq[0][j][p];
+            bsc1[j] = bsc[j];
+        }
+        load_w(0);
+        Raw Q0, Q1;
+        const int ntile = (int)(t_end - t_beg);
+        if (ntile > 0) { prefetch(0, Q0); prefetch(1, Q1); }
+        for (int tl = 0; tl < ntile; ++tl) {
+            const int b0 = (tl & 1) * 2;
+            stage(b0, 0, Q0);
+            stage(b0 + 1, 1, Q1);
+            const int tn = tl + 1 < ntile ? tl + 1 : tl;          // past the last tile: an unused re-load of it
+            prefetch(2 * tn, Q0);
+            prefetch(2 * tn + 1, Q1);
+            __syncthreads();       // this tile's two buffers complete; the other parity's readers finished before their barrier
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const char* sb = smem + (b0 + c) * BUFSZ;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const char* rec = sb + (mt * 32 + r) * PSTRIDE;
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + h * 16));
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4*)(rec + 32 + h * 16));
+                    const uint4 aq = *(const uint4*)(rec + 64 + h * 16);
+                    const int as = *(const unsigned char*)(rec + 96 + h);
+                    i32x8 a4 = {};
+                    a4[0] = aq.x; a4[1] = aq.y; a4[2] = aq.z; a4[3] = aq.w;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const uint4* wb = c ? bq1[j] : bq[0][j];
+                        const f16x8 b0f = __builtin_bit_cast(f16x8, wb[0]), b1f = __builtin_bit_cast(f16x8, wb[1]);
+                        i32x8 b4 = {};
+                        b4[0] = wb[2].x; b4[1] = wb[2].y; b4[2] = wb[2].z; b4[3] = wb[2].w;
+                        const int bsv = (int)(c ? bsc1[j] : bsc[j]);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0f, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1f, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, b4, acc[mt][j], 4, 4, 0, as, 0, bsv);
+                    }
+                }
+            }
+            ctx_epilogue((t_beg + tl) * TP);
+        }
+    } else {
     Raw R0, R1;
     if (niter > 0) { prefetch(0, R0); load_w(0); prefetch(niter > 1 ? 1 : 0, R1); }
     auto body = [&](int it, Raw& R) __attribute__((always_inline)) {
@@ -313,71 +444,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
                 for (int i = 0; i < 16; ++i)
                     if (p0 + mt * 32 + acc_row(i, h) < a.hw) run_max = fmaxf(run_max, acc[mt][0][i]);
         } else if (EPI == LA_CTX) {
-            const bool full_tile = p0 + TP <= a.hw;
-            if (online) {
-                // running max of this lane's k channel over the workgroup's pixels; rescale what has been accumulated
-                float tmax = -INFINITY;
-                if (full_tile) {        // no per-pixel masks; v_max3 on the raw accumulators (fmaxf quiets every input first)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int i = 0; i < 16; i += 2) {
-                            const float x0 = acc[mt][0][i], x1 = acc[mt][0][i + 1];
-                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(tmax), "v"(x0), "v"(x1));
-                        }
-                } else {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (p0 + mt * 32 + acc_row(i, h) < a.hw) tmax = fmaxf(tmax, acc[mt][0][i]);
-                }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                const float m_new = fmaxf(kmx, tmax);
-                const float f = (m_new == kmx) ? 1.f : __expf(kmx - m_new);     // kmx = -inf on the first tile -> 0 (accumulators are 0)
-                if (__any(f != 1.f)) {                          // wave-uniform: after the first tiles the running max rarely moves
-                    zsum *= f;
-#pragma unroll
-                    for (int s_ = 0; s_ < 16; ++s_) cacc[s_] *= __shfl(f, acc_row(s_, h));   // row d of ctx lives on lane d
-                }
-                kmx = m_new;
-            }
-            // ctx[d][e] += sum_pixel exp(k[pixel][d] - kmx[d]) v[pixel][e]: both accumulators (lane = channel, registers =
-            // pixels) are operands of a product over their row index as they stand (split_frag)
-            const float kl = kmx * 1.44269504088896340736f;   // exp(k - kmx) = exp2(k log2e - kmx log2e): one FMA + v_exp_f32
-            auto accum = [&](auto full) __attribute__((always_inline)) {
-            constexpr bool FULL = decltype(full)::value;      // whole tile inside the image: no per-pixel masks
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_) {
-                    float ev[8], vv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = 8 * s_ + j;
-                        const bool ok = FULL || p0 + mt * 32 + acc_row(i, h) < a.hw;
-                        ev[j] = ok ? __builtin_amdgcn_exp2f(fmaf(acc[mt][0][i], 1.44269504088896340736f, -kl)) : 0.f;
-                        vv[j] = ok ? acc[mt][NT - 1][i] : 0.f;
-                        zsum += ev[j];
-                    }
-                    // ONE fp16 product: the fp16 roundings of e (in [0,1]) and v are independent across the hw pixels the sum
-                    // runs over, so their relative contribution to ctx shrinks like 2^-12 / sqrt(hw) -- far below the
-                    // projection's own error; the normaliser z is summed in fp32 above
-                    // (F16F4 mode only; the other modes keep the fp32-grade hi/lo product)
-                    if (F4) {
-                        f16x8 eh, vh;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { eh[j] = (_Float16)ev[j]; vh[j] = (_Float16)vv[j]; }
-                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, vh, cacc, 0, 0, 0);
-                    } else {
-                        f16x8 eh, el, vh, vl;
-                        split_frag(ev, eh, el);
-                        split_frag(vv, vh, vl);
-                        cacc = mfma_f16x3(eh, el, vh, vl, cacc);
-                    }
-                }
-            };
-            if (full_tile) accum(std::true_type{}); else accum(std::false_type{});
+            ctx_epilogue(p0);
         } else {
             const float scale = 0.17677669529663688110f;         // 32^-0.5
             const float inv_hw = 1.f / (float)a.hw;
@@ -420,6 +487,8 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     int it2 = 0;
     for (; it2 + 1 < niter; it2 += 2) { body(it2, R0); body(it2 + 1, R1); }
     if (it2 < niter) body(it2, R0);
+
+    }
 
     if (EPI == LA_KMAX) {
         run_max = fmaxf(run_max, __shfl_xor(run_max, 32));
@@ -818,12 +887,20 @@ LaSplit la_split(long long hw) {
     return LaSplit{(int)tpw, (int)((tiles + tpw - 1) / tpw)};
 }
 
+int g_la_ctx_one = 1;     // tedm_set_tuning("la_ctx_one", 0|1): single-barrier context sweep at C = 64 (f16f4)
+
 template <int EPI>
 int launch_la(const LaArgs& a, int prec, hipStream_t st) {
     dim3 grid(a.B * a.S), block(256);
     constexpr int TP = LaTile<EPI>::MT * 32;
     const size_t gl = (size_t)a.C * sizeof(float);                        // PreNorm gain
     const size_t lds1 = 2 * (size_t)TP * pstride(prec) + gl, lds2 = 4 * (size_t)TP * pstride(prec) + gl;   // one / two precision planes, double buffered
+    if constexpr (EPI == LA_CTX) {
+        if (prec == TEDM_PREC_F16F4 && a.C == 2 * KC && g_la_ctx_one) {
+            hipLaunchKernelGGL((la_proj_kernel<LA_CTX, TEDM_PREC_F16F4, true>), grid, block, 2 * lds1 - gl, st, a);
+            return LAUNCH_OK();
+        }
+    }
     if (prec == TEDM_PREC_F16F4) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_F16F4>), grid, block, lds1, st, a);
     else if (prec == TEDM_PREC_BF16) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_BF16>), grid, block, lds1, st, a);
     else if (prec == TEDM_PREC_FP16X2) hipLaunchKernelGGL((la_proj_kernel<EPI, TEDM_PREC_FP16X2>), grid, block, lds1, st, a);
@@ -846,6 +923,11 @@ int op_linattn_fused(int sweep, const float* x, int C, const float* g, const flo
     if (sweep == LA_KMAX) return launch_la<LA_KMAX>(a, prec, st);
     if (sweep == LA_CTX) return launch_la<LA_CTX>(a, prec, st);
     return launch_la<LA_QOUT>(a, prec, st);
+}
+
+int la_set_tuning(const char* key, int v) {
+    if (!strcmp(key, "la_ctx_one") && (v == 0 || v == 1)) { g_la_ctx_one = v; return TEDM_OK; }
+    return TEDM_EINVAL;
 }
 
 // The fused q sweep + to_out + LayerNorm + residual (F16F4 weight packs; heads == 4, C in {64, 128, 256}).

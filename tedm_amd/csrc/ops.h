@@ -72,6 +72,7 @@ size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo);
 int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
                        int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, hipStream_t st);
 int wgrad_set_tuning(const char* key, int v);
+int la_set_tuning(const char* key, int v);
 int wgrad_mfma_set_tuning(const char* key, int v);
 
 // backward.hip

@@ -1117,6 +1117,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!strcmp(key, "act_q16_max_c") && value >= 0 && value <= 512) { g_act_q16_max_c = value; return TEDM_OK; }
     if (!strcmp(key, "bench_q16") && value >= 0 && value <= 7) { g_bench_q16 = value; return TEDM_OK; }
     if (wgrad_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
+    if (la_set_tuning(key, value) == TEDM_OK) return TEDM_OK;
     const int rc = conv_set_tuning(key, value);
     return rc == TEDM_OK ? rc : fail(rc, "unknown tuning key '%s' or bad value %d", key, value);
 }
