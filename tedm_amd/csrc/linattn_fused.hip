@@ -64,6 +64,26 @@ TEDM_DEVFN f32x16 mfma_f16x3(const f16x8& ah, const f16x8& al, const f16x8& bh, 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
 }
 
+// LayerNorm statistics (rstd, mean * rstd) of a 64-channel pixel whose channels sit as 2 x 8 values on each lane of a quad
+// (ln_stats_kernel's two-pass formula: mean, then the centred sum of squares)
+TEDM_DEVFN float quad_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+TEDM_DEVFN float2 quad_ln_stats(const float4 (&a)[2], const float4 (&b)[2]) {
+    float s = ((a[0].x + a[0].y) + (a[0].z + a[0].w)) + ((a[1].x + a[1].y) + (a[1].z + a[1].w))
+            + ((b[0].x + b[0].y) + (b[0].z + b[0].w)) + ((b[1].x + b[1].y) + (b[1].z + b[1].w));
+    const float mean = quad_sum(s) * (1.f / 64.f);
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float t;
+        t = a[i].x - mean; d2 = fmaf(t, t, d2); t = a[i].y - mean; d2 = fmaf(t, t, d2);
+        t = a[i].z - mean; d2 = fmaf(t, t, d2); t = a[i].w - mean; d2 = fmaf(t, t, d2);
+        t = b[i].x - mean; d2 = fmaf(t, t, d2); t = b[i].y - mean; d2 = fmaf(t, t, d2);
+        t = b[i].z - mean; d2 = fmaf(t, t, d2); t = b[i].w - mean; d2 = fmaf(t, t, d2);
+    }
+    const float rstd = rsqrtf(quad_sum(d2) * (1.f / 64.f) + 1e-5f);
+    return make_float2(rstd, mean * rstd);
+}
+
 constexpr int KS = 2, KC = 16 * KS;             // channels per staged chunk
 // LDS bytes per pixel per plane (odd multiples of 16): bf16 / fp16 planes 80; F16F4 one 112-byte record
 // [fp16 x32 | fp4 residual x32 | fp4 copy x32 | 2 scale bytes | pad] exactly as conv_igemm.inc stages it
@@ -77,9 +97,13 @@ template <int EPI> struct LaTile { static constexpr int MT = EPI == LA_CTX ? LA_
 // ONE (CTX sweep, F16F4, C = 64): both 32-channel chunks of a 64-pixel tile are staged in front of ONE barrier (four LDS buffers:
 // tile parity x chunk), the k / v weights of both chunks stay in registers and the next tile's activations are in flight for a
 // whole tile period -- half the barriers per byte of the chunk-by-chunk loop.
-template <int EPI, int PREC, bool ONE = false>
+// ONE == 2: the same, and the PreNorm LayerNorm statistics come from the kernel itself (a.lnstats unused): a thread holds 8 + 8 of
+// a pixel's 64 channels (both chunks in registers), the four threads of a quad the whole pixel -- mean and centred variance are
+// two quad reductions (the formula of ln_stats_kernel), which drops the separate statistics pass over the tensor.
+template <int EPI, int PREC, int ONE = 0>
 __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
     static_assert(!ONE || (EPI == LA_CTX && PREC == TEDM_PREC_F16F4), "ONE: the C = 64 context sweep in f16f4");
+    constexpr bool SELF = ONE == 2;
     constexpr int MT = LaTile<EPI>::MT, TP = MT * 32, NIT = MT / 2;   // TP*4 pieces / 256 threads
     constexpr bool F4 = PREC == TEDM_PREC_F16F4;
     constexpr int PSTRIDE = pstride(PREC);
@@ -153,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
             const size_t gp = (size_t)n * a.hw + p;
             const float4* src = (const float4*)(a.x + gp * a.C + cb);
             rv[k][0] = src[0]; rv[k][1] = src[1];
-            rs[k] = *(const float2*)(a.lnstats + gp * 2);
+            if (!SELF) rs[k] = *(const float2*)(a.lnstats + gp * 2);
         }
     };
     auto stage = [&](int buf, int c, const Raw& R) __attribute__((always_inline)) {
@@ -310,6 +334,13 @@ __global__ __launch_bounds__(256, 2) void la_proj_kernel(LaArgs a) {
         if (ntile > 0) { prefetch(0, Q0); prefetch(1, Q1); }
         for (int tl = 0; tl < ntile; ++tl) {
             const int b0 = (tl & 1) * 2;
+            if constexpr (SELF) {
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const float2 st2 = quad_ln_stats(Q0.v[k], Q1.v[k]);
+                    Q0.s[k] = st2; Q1.s[k] = st2;
+                }
+            }
             stage(b0, 0, Q0);
             stage(b0 + 1, 1, Q1);
             const int tn = tl + 1 < ntile ? tl + 1 : tl;          // past the last tile: an unused re-load of it
@@ -520,8 +551,10 @@ struct LaTailArgs {
 
 // RAGGED: hw is not a multiple of the 64-pixel tile -- the output stores of the last tile are masked per lane.  The even
 // case keeps every VMEM instruction of the tile loop outside conditional code (exact vmcnt counts, see la_proj_kernel).
-template <int NT2, bool RAGGED>
+// SELF (C = 64): PreNorm LayerNorm statistics from the kernel's own registers (quad_ln_stats), a.lnstats unused.
+template <int NT2, bool RAGGED, bool SELF = false>
 __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
+    static_assert(!SELF || NT2 == 2, "own LayerNorm statistics: both chunks of a pixel in registers (C = 64)");
     constexpr int MT = 2, TP = 64, PS = 112;                  // 64-pixel tiles, F16F4 records
     constexpr int NTH = NT2 / 2;                              // cout tiles per wave in the tail (two waves share a pixel group)
     constexpr int STG = TP * PS;                              // one staging buffer
@@ -574,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
         const size_t gp = (size_t)n * a.hw + p;
         const float4* src = (const float4*)(a.x + gp * a.C + cb);
         rv[0] = src[0]; rv[1] = src[1];
-        rs = *(const float2*)(a.lnstats + gp * 2);
+        if (!SELF) rs = *(const float2*)(a.lnstats + gp * 2);
     };
     auto stage = [&](int buf, int c, const Raw& R) __attribute__((always_inline)) {
         const float4 (&rv)[2] = R.v; const float2& rs = R.s; const bool rok = R.ok;
@@ -680,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
             prefetch(tn, wrap ? c + 2 - NC : c + 2, R);
         };
         if constexpr (ONE) {
+            if constexpr (SELF) { R0.s = quad_ln_stats(R0.v, R1.v); R1.s = R0.s; }
             stage(0, 0, R0);
             stage(1, 1, R1);
             const long long tn = t + 1 < t_end ? t + 1 : t;    // past the last tile: an unused re-load of it
@@ -896,8 +930,9 @@ int launch_la(const LaArgs& a, int prec, hipStream_t st) {
     const size_t gl = (size_t)a.C * sizeof(float);                        // PreNorm gain
     const size_t lds1 = 2 * (size_t)TP * pstride(prec) + gl, lds2 = 4 * (size_t)TP * pstride(prec) + gl;   // one / two precision planes, double buffered
     if constexpr (EPI == LA_CTX) {
-        if (prec == TEDM_PREC_F16F4 && a.C == 2 * KC && g_la_ctx_one) {
-            hipLaunchKernelGGL((la_proj_kernel<LA_CTX, TEDM_PREC_F16F4, true>), grid, block, 2 * lds1 - gl, st, a);
+        if (prec == TEDM_PREC_F16F4 && a.C == 2 * KC && (g_la_ctx_one || !a.lnstats)) {
+            if (a.lnstats) hipLaunchKernelGGL((la_proj_kernel<LA_CTX, TEDM_PREC_F16F4, 1>), grid, block, 2 * lds1 - gl, st, a);
+            else hipLaunchKernelGGL((la_proj_kernel<LA_CTX, TEDM_PREC_F16F4, 2>), grid, block, 2 * lds1 - gl, st, a);
             return LAUNCH_OK();
         }
     }
@@ -915,6 +950,7 @@ int op_linattn_fused(int sweep, const float* x, int C, const float* g, const flo
                      long long hw, int heads, float* kmax_part, const float* kmax, float* ctx_part, const float* ctx,
                      float* o, int prec, hipStream_t st) {
     if (heads != 4 || C % KC) return TEDM_EINVAL;
+    if (!lnstats && !la_self_ln_supported(C, heads, prec, sweep)) return TEDM_EINVAL;
     LaArgs a{};
     a.x = x; a.C = C; a.g = g; a.lnstats = lnstats; a.wpk = wpk; a.B = B; a.hw = hw; a.heads = heads;
     a.kmax_part = kmax_part; a.kmax = kmax; a.ctx_part = ctx_part; a.ctx = ctx; a.o = o;
@@ -925,6 +961,10 @@ int op_linattn_fused(int sweep, const float* x, int C, const float* g, const flo
     return launch_la<LA_QOUT>(a, prec, st);
 }
 
+// The context sweep and the fused tail can take the PreNorm statistics from their own registers (lnstats == nullptr)
+bool la_self_ln_supported(int C, int heads, int prec, int sweep) {
+    return prec == TEDM_PREC_F16F4 && heads == 4 && C == 64 && (sweep == LA_CTX || sweep == -1 /* fused tail */);
+}
 int la_set_tuning(const char* key, int v) {
     if (!strcmp(key, "la_ctx_one") && (v == 0 || v == 1)) { g_la_ctx_one = v; return TEDM_OK; }
     return TEDM_EINVAL;
@@ -946,7 +986,11 @@ int op_linattn_qout_tail(const float* x, int C, const float* g, const float* lns
     a.tpw = (int)tpw; a.S = (int)((tiles + tpw - 1) / tpw);
     const size_t lds = 2 * 64 * 112 + 64 * 4 * 112 + 64 * 2 * sizeof(float2) + 3 * (size_t)C * sizeof(float);
     dim3 grid(B * a.S), block(256);
-    if (hw % 64) {
+    if (!lnstats) {
+        if (C != 64) return TEDM_EINVAL;
+        if (hw % 64) hipLaunchKernelGGL((la_qout_tail_kernel<2, true, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((la_qout_tail_kernel<2, false, true>), grid, block, lds, st, a);
+    } else if (hw % 64) {
         if (C == 64) hipLaunchKernelGGL((la_qout_tail_kernel<2, true>), grid, block, lds, st, a);
         else if (C == 128) hipLaunchKernelGGL((la_qout_tail_kernel<4, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((la_qout_tail_kernel<8, true>), grid, block, lds, st, a);

@@ -47,6 +47,7 @@ int la_fused_wgs_per_image(int sweep, long long hw);
 // merge of the online-max context partials (sweep 1 called with kmax == NULL; partial stride 1024+64 floats per head)
 int op_linattn_ctx_merge(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st);
 bool la_tail_supported(int C, int heads, int prec);
+bool la_self_ln_supported(int C, int heads, int prec, int sweep);   // lnstats == nullptr accepted (sweep: 1 = context, -1 = fused tail)
 int op_linattn_qout_tail(const float* x, int C, const float* g, const float* lnstats, const void* wqkv, const float* ctx,
                          const void* wout, const float* bias, const float* g_out, int B, long long hw, int heads, float* out,
                          hipStream_t st);

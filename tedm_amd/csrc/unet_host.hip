@@ -192,6 +192,7 @@ int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1|2) BEFORE tedm_un
                            // the full-resolution level keep the fp4 cross terms.  2: every k x k conv with >= 256 output channels.
 int g_conv_up_split = 1;   // tedm_set_tuning("conv_up_split", 0|1): Upsample as four 2x2 parity convs on the low-resolution image
 int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
+int g_la_self_ln = 1;  // tedm_set_tuning("la_self_ln", 0|1): the fused linear-attention kernels compute the PreNorm statistics themselves where they can (C = 64, f16f4)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
 
 }  // namespace
@@ -446,6 +447,13 @@ struct Fwd {
     }
 
     // Residual(PreNorm(LinearAttention)) (models/unet_model.py:178-210, :29-36, :64-73)
+    // The fused linear-attention kernels compute the PreNorm LayerNorm statistics themselves when a pixel's channels fit their
+    // registers (C = 64, f16f4: linattn_fused.hip): the block in front then skips the statistics (ln == nullptr below).
+    bool linattn_self_ln(const AttnPlan& a) const {
+        const int heads = u->cfg.heads;
+        return g_la_self_ln && g_la_fused == 2 && g_la_tail && a.linear && la_tail_supported(a.C, heads, prec) && a.out.enc == ENC_F16F4 &&
+               a.qkv.enc == ENC_F16F4 && la_self_ln_supported(a.C, heads, prec, 1) && la_self_ln_supported(a.C, heads, prec, -1);
+    }
     int linattn(const AttnPlan& a, const float* x, const float* ln, int H, int W, float* out_buf, float** out) {
         const long long hw = (long long)H * W, P = (long long)B * hw;
         const int C = a.C, C3 = 3 * u->hidden, heads = u->cfg.heads;
@@ -569,9 +577,10 @@ struct Fwd {
             CHECK(resblock(L.b1, cur, C, nullptr, 0, h, w, &h1, nullptr));
             if (cur != r) A->release(cur);
             hs.push_back(h1);
-            CHECK(resblock(L.b2, h1, C, nullptr, 0, h, w, &x2, &ln));
+            ln = nullptr;
+            CHECK(resblock(L.b2, h1, C, nullptr, 0, h, w, &x2, linattn_self_ln(L.attn) ? nullptr : &ln));
             CHECK(linattn(L.attn, x2, ln, h, w, nullptr, &att));
-            A->release(x2); A->release(ln);
+            A->release(x2); if (ln) A->release(ln);
             hs.push_back(att);
             const int Cn = u->dims[i + 1];
             if (L.tail_kind == 0) {
@@ -605,11 +614,12 @@ struct Fwd {
             CHECK(resblock(L.b1, cur, dout, s, din, h, w, &y1, nullptr));
             A->release(cur); A->release(s);
             s = hs.back(); hs.pop_back();
-            CHECK(resblock(L.b2, y1, dout, s, din, h, w, &y2, &ln));
+            ln = nullptr;
+            CHECK(resblock(L.b2, y1, dout, s, din, h, w, &y2, linattn_self_ln(L.attn) ? nullptr : &ln));
             A->release(y1); A->release(s);
             float* fo = (feat_out && feat_out[i]) ? feat_out[i] : nullptr;
             CHECK(linattn(L.attn, y2, ln, h, w, fo, &att));
-            A->release(y2); A->release(ln);
+            A->release(y2); if (ln) A->release(ln);
             const bool last = i == nres - 1;
             if (last && taps_only) { A->release(att); cur = nullptr; break; }
             if (L.tail_kind == 2) {
@@ -1111,6 +1121,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!key) return fail(TEDM_EINVAL, "null key");
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
+    if (!strcmp(key, "la_self_ln") && (value == 0 || value == 1)) { g_la_self_ln = value; return TEDM_OK; }
     if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
     if (!strcmp(key, "deep_fp16") && value >= 0 && value <= 2) { g_deep_fp16 = value; return TEDM_OK; }
     if (!strcmp(key, "act_q16") && (value == 0 || value == 1)) { g_act_q16 = value; return TEDM_OK; }

@@ -523,6 +523,29 @@ def test_linattn_fused_tail_matches_separate_kernels(lib, dev, golden_dir):
         assert not torch.equal(res[1][0], res[0][0])          # the two paths really differ (the tuning key took effect)
 
 
+def test_linattn_own_layernorm_statistics(lib, dev):
+    """f16f4, 64-channel levels: the context sweep and the fused tail take the PreNorm LayerNorm statistics from their own registers
+    (no ln_stats pass / statistics output of the block in front) -- against the same kernels fed the statistics, on eps and the
+    decoder taps; 96x72 exercises the ragged last tile."""
+    from tedm_amd import _lib
+    m = make_unet(64, 0, dev, 'f16f4')
+    g = torch.Generator().manual_seed(22)
+    for shape in ((2, 1, 64, 64), (1, 1, 96, 72)):
+        x, t = torch.randn(*shape, generator=g).to(dev), torch.randint(0, 1000, (shape[0],), generator=g).to(dev)
+        res = {}
+        try:
+            for mode in (1, 0):
+                _lib.check(lib.tedm_set_tuning(b'la_self_ln', mode), 'tune')
+                with torch.no_grad():
+                    res[mode] = m.native_forward(x, t, want_taps=True)
+        finally:
+            lib.tedm_set_tuning(b'la_self_ln', 1)
+        # statistics that differ in the last bit decorrelate the f16f4 operand roundings downstream (see the test above)
+        assert rel(res[1][0], res[0][0]) < EPS_GATE / 2
+        for a_, b_ in zip(res[1][1], res[0][1]):
+            assert rel(a_, b_) < EPS_GATE / 2
+
+
 def test_vs_oracle_ragged_shape(dev, unet64):
     """B=3, 96x72 (not a power of two, H != W) against the oracle incl. module trace."""
     from oracle import unet_ref as O
