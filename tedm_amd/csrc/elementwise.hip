@@ -682,6 +682,86 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// final_res_block's tail fused with final_conv (inference, models/unet_model.py:166-175 + :331,368):
+//   eps[o] = final_conv( res_conv(cat(x1, x2)) + silu(GN2(y2)) )[o]
+//          = (Wf W_res)[o] . cat(x1, x2)  +  Wf[o] . silu(a y2 + b)  +  (Wf b_res + bf)[o]
+// Both 1x1 convolutions are linear, so the 64-channel block output never has to exist: one pass reads x1, x2, y2 and writes OD
+// values per pixel, in fp32 (no MFMA: 192 FMAs + 64 SiLU per pixel against 768 bytes of HBM reads).
+// fold: wfold[o][0..C1+C2) = Wf[o] W_res, wfold[o][C1+C2] = Wf[o] . b_res + bf[o]        (one block)
+__global__ __launch_bounds__(256) void final_fold_kernel(const float* __restrict__ wf, const float* __restrict__ bf,
+                                                         const float* __restrict__ wres, const float* __restrict__ bres,
+                                                         int OD, int C, int Cin, float* __restrict__ wfold) {
+    for (int i = threadIdx.x; i < OD * (Cin + 1); i += blockDim.x) {
+        const int o = i / (Cin + 1), j = i - o * (Cin + 1);
+        float s = 0.f;
+        if (j < Cin) { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], wres[(size_t)c * Cin + j], s); }
+        else { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], bres ? bres[c] : 0.f, s); s += bf ? bf[o] : 0.f; }
+        wfold[i] = s;
+    }
+}
+
+// x1, x2, y2: (P, C) NHWC with the same C; a pixel's channels over lpp lanes, V float4 per lane; two pixel groups per iteration
+template <int V>
+__global__ __launch_bounds__(256) void final_fused_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                          const float* __restrict__ y, const float* __restrict__ ga,
+                                                          const float* __restrict__ gb, const float* __restrict__ wf,
+                                                          const float* __restrict__ wfold, float* __restrict__ out,
+                                                          long long P, long long hw, int C, int OD, int lpp) {
+    const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    constexpr int U = 2;
+    for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw * U) {
+        float4 yy[U][V], xa[U][V], xb[U][V], aa[U][V], bb[U][V];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pu = p0 + u * nwaves * ppw + sub;
+            ok[u] = pu < P;
+            const long long p = ok[u] ? pu : P - 1;             // unconditional loads, clamped address
+            const int n = (int)(p / hw);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int c = (v * lpp + q) * 4;
+                yy[u][v] = *(const float4*)(y + (size_t)p * C + c);
+                xa[u][v] = *(const float4*)(x1 + (size_t)p * C + c);
+                xb[u][v] = *(const float4*)(x2 + (size_t)p * C + c);
+                aa[u][v] = *(const float4*)(ga + (size_t)n * C + c);
+                bb[u][v] = *(const float4*)(gb + (size_t)n * C + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + u * nwaves * ppw + sub;
+            float4 sv[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                sv[v].x = silu_f(fmaf(aa[u][v].x, yy[u][v].x, bb[u][v].x)); sv[v].y = silu_f(fmaf(aa[u][v].y, yy[u][v].y, bb[u][v].y));
+                sv[v].z = silu_f(fmaf(aa[u][v].z, yy[u][v].z, bb[u][v].z)); sv[v].w = silu_f(fmaf(aa[u][v].w, yy[u][v].w, bb[u][v].w));
+            }
+            for (int o = 0; o < OD; ++o) {
+                const float* wo = wfold + (size_t)o * (2 * C + 1);
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int c = (v * lpp + q) * 4;
+                    const float4 w0 = *(const float4*)(wf + (size_t)o * C + c);
+                    const float4 w1 = *(const float4*)(wo + c), w2 = *(const float4*)(wo + C + c);
+                    s = fmaf(sv[v].x, w0.x, s); s = fmaf(sv[v].y, w0.y, s); s = fmaf(sv[v].z, w0.z, s); s = fmaf(sv[v].w, w0.w, s);
+                    s = fmaf(xa[u][v].x, w1.x, s); s = fmaf(xa[u][v].y, w1.y, s); s = fmaf(xa[u][v].z, w1.z, s); s = fmaf(xa[u][v].w, w1.w, s);
+                    s = fmaf(xb[u][v].x, w2.x, s); s = fmaf(xb[u][v].y, w2.y, s); s = fmaf(xb[u][v].z, w2.z, s); s = fmaf(xb[u][v].w, w2.w, s);
+                }
+                s = group_sum(s, lpp);
+                if (ok[u] && q == 0) {
+                    const long long n = p / hw, pix = p - n * hw;
+                    out[((size_t)n * OD + o) * hw + pix] = s + wo[2 * C];
+                }
+            }
+        }
+    }
+}
+
 // per-(sample, channel) 1/max(||.||_2 over pixels, 1e-12) from a (sum, sumsq) slab:
 // F.normalize(dim=-1) of models/unet_model.py:23,234.  One block per (sample, 64-channel group):
 // 4 waves split the slab entries, lanes own channels (coalesced), LDS combines the 4 partials.
@@ -928,6 +1008,22 @@ int op_final_conv(const float* x, const float* w, const float* bias, float* out,
                m.lpp);
     return LAUNCH_OK();
 }
+
+// wfold: OD * (2C + 1) floats of scratch (written here, read by the fused kernel on the same stream)
+int op_final_fused(const float* x1, const float* x2, const float* y2, const float* ga, const float* gb, const float* wres,
+                   const float* bres, const float* wf, const float* bf, float* wfold, float* out_nchw, int B, long long hw,
+                   int C, int OD, hipStream_t st) {
+    PixMap m;
+    if (!pixmap(C, m) || m.v > 2 || OD < 1) return TEDM_EINVAL;
+    const long long P = (long long)B * hw;
+    hipLaunchKernelGGL(final_fold_kernel, dim3(1), dim3(256), 0, st, wf, bf, wres, bres, OD, C, 2 * C, wfold);
+    switch (m.v) {
+        case 1: hipLaunchKernelGGL(final_fused_kernel<1>, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, x1, x2, y2, ga, gb, wf, wfold, out_nchw, P, hw, C, OD, m.lpp); break;
+        default: hipLaunchKernelGGL(final_fused_kernel<2>, dim3(pix_grid(P, m.lpp)), dim3(256), 0, st, x1, x2, y2, ga, gb, wf, wfold, out_nchw, P, hw, C, OD, m.lpp); break;
+    }
+    return LAUNCH_OK();
+}
+bool final_fused_supported(int C1, int C2, int C) { PixMap m; return C1 == C && C2 == C && pixmap(C, m) && m.v <= 2; }
 
 int op_colnorm_finalize(const float* slab, int E, int C, int B, float* inv, hipStream_t st) {
     hipLaunchKernelGGL(colnorm_finalize_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 0, st, slab, E, C, B, inv);

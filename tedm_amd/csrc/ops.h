@@ -23,6 +23,10 @@ int op_q16_encode(const float* x, void* q, int B, int H, int W, int C, hipStream
 int op_q16_decode(const void* q, float* x, int B, int H, int W, int C, hipStream_t st);
 int op_ln_stats(const float* x, float* lnstats, long long P, int C, hipStream_t st);
 int op_ln_res(const float* z, const float* g, const float* x, float* out, long long P, int C, hipStream_t st);
+int op_final_fused(const float* x1, const float* x2, const float* y2, const float* ga, const float* gb, const float* wres,
+                   const float* bres, const float* wf, const float* bf, float* wfold, float* out_nchw, int B, long long hw,
+                   int C, int OD, hipStream_t st);
+bool final_fused_supported(int C1, int C2, int C);
 int op_final_conv(const float* x, const float* w, const float* bias, float* out_nchw, int B, long long hw, int C,
                   int OD, hipStream_t st);
 int op_colnorm_finalize(const float* slab, int E, int C, int B, float* inv, hipStream_t st);

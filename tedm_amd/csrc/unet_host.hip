@@ -192,6 +192,7 @@ int g_deep_fp16 = 1;       // tedm_set_tuning("deep_fp16", 0|1|2) BEFORE tedm_un
                            // the full-resolution level keep the fp4 cross terms.  2: every k x k conv with >= 256 output channels.
 int g_conv_up_split = 1;   // tedm_set_tuning("conv_up_split", 0|1): Upsample as four 2x2 parity convs on the low-resolution image
 int g_la_tail = 1;    // tedm_set_tuning("la_tail", 0|1): q sweep fused with to_out + LayerNorm + residual (f16f4, C <= 256)
+int g_final_fuse = 1;  // tedm_set_tuning("final_fuse", 0|1): final_res_block's res_conv + silu(GN2) folded with final_conv (inference)
 int g_la_self_ln = 1;  // tedm_set_tuning("la_self_ln", 0|1): the fused linear-attention kernels compute the PreNorm statistics themselves where they can (C = 64, f16f4)
 int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 three fused sweeps (kmax, ctx, qout), 2 two sweeps (online max)
 
@@ -405,15 +406,17 @@ struct Fwd {
     }
 
     // ResnetBlock (models/unet_model.py:138-175).  out_buf may be caller-provided.
+    // fuse_final (final_res_block, inference; final_eps = the eps output, null in a dry run): the block's tail -- res_conv + silu(GN2) -- is folded with final_conv into one
+    // elementwise pass (elementwise.hip: final_fused_kernel); the block output is never written and *out stays nullptr.
     int resblock(const ResPlan& r, const float* x1, int C1, const float* x2, int C2, int H, int W, float** out,
-                 float** lnstats) {
+                 float** lnstats, bool fuse_final = false, float* final_eps = nullptr) {
         const long long hw = (long long)H * W;
         const int C = r.cout;
         const int E = conv_stats_entries(3, 1, C, H, W);
         float* slab = A->alloc((size_t)B * E * C * 2);
         // Q16 storage of the two branch tensors (written once, read once through a GroupNorm prologue) on the HBM-bound levels
         // of the fast inference mode: 2 bytes per element instead of 4, +1e-4 on eps in quadrature (common.h)
-        const bool q = q16 && g_act_q16 && prec == TEDM_PREC_F16F4 && C <= g_act_q16_max_c && C % 32 == 0 && (C & (C - 1)) == 0 && C <= 512;
+        const bool q = !fuse_final && q16 && g_act_q16 && prec == TEDM_PREC_F16F4 && C <= g_act_q16_max_c && C % 32 == 0 && (C & (C - 1)) == 0 && C <= 512;
         const size_t qf = (q16_bytes(B, H, W, C) + 3) / 4;                       // floats of a Q16 buffer
         float* y1 = A->alloc(q ? qf : (size_t)B * hw * C);
         float* ga = A->alloc((size_t)B * C);
@@ -428,6 +431,15 @@ struct Fwd {
         OP("gn_finalize", 0.0, 8.0 * B * E * C,
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
                           u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, nullptr, st));
+        if (fuse_final) {
+            float* wfold = A->alloc((size_t)u->out_dim * (2 * C + 1));
+            OP("final_fused", 2.0 * B * hw * u->out_dim * 3 * C, 4.0 * B * hw * (3 * C + u->out_dim),
+               op_final_fused(x1, x2, y2, ga, gb, u->P(r.res.key + ".weight"), r.res.has_bias ? u->P(r.res.key + ".bias") : nullptr,
+                              u->P("final_conv.weight"), u->P("final_conv.bias"), wfold, final_eps, B, hw, C, u->out_dim, st));
+            A->release(wfold); A->release(y2); A->release(slab); A->release(ga); A->release(gb);
+            *out = nullptr;
+            return TEDM_OK;
+        }
         float* o = A->alloc((size_t)B * hw * C);
         float* ln = lnstats ? A->alloc((size_t)B * hw * 2) : nullptr;
         if (r.has_res) {
@@ -637,11 +649,13 @@ struct Fwd {
         }
         if (!taps_only) {
             float* f;
-            CHECK(resblock(u->fin, cur, dim, r, u->init_dim, h, w, &f, nullptr));
+            // (not under TEDM_FWD_TRACE: the trace records final_res_block's output)
+            const bool fuse = g_final_fuse && !(flags & TEDM_FWD_TRACE) && u->fin.has_res && final_fused_supported(dim, u->init_dim, u->fin.cout);
+            CHECK(resblock(u->fin, cur, dim, r, u->init_dim, h, w, &f, nullptr, fuse, eps_out));
             A->release(cur);
-            OP("final_conv1x1", 2.0 * B * h * w * dim * u->out_dim, 4.0 * B * h * w * (dim + u->out_dim),
+            if (!fuse) OP("final_conv1x1", 2.0 * B * h * w * dim * u->out_dim, 4.0 * B * h * w * (dim + u->out_dim),
                op_final_conv(f, u->P("final_conv.weight"), u->P("final_conv.bias"), eps_out, B, (long long)h * w, dim, u->out_dim, st));
-            A->release(f);
+            if (!fuse) A->release(f);
         }
         A->release(r);
         if (filmbuf) A->release(filmbuf);
@@ -1122,6 +1136,7 @@ int tedm_set_tuning(const char* key, int value) {
     if (!strcmp(key, "la_fused") && value >= 0 && value <= 2) { g_la_fused = value; return TEDM_OK; }
     if (!strcmp(key, "la_tail") && (value == 0 || value == 1)) { g_la_tail = value; return TEDM_OK; }
     if (!strcmp(key, "la_self_ln") && (value == 0 || value == 1)) { g_la_self_ln = value; return TEDM_OK; }
+    if (!strcmp(key, "final_fuse") && (value == 0 || value == 1)) { g_final_fuse = value; return TEDM_OK; }
     if (!strcmp(key, "conv_up_split") && (value == 0 || value == 1)) { g_conv_up_split = value; return TEDM_OK; }
     if (!strcmp(key, "deep_fp16") && value >= 0 && value <= 2) { g_deep_fp16 = value; return TEDM_OK; }
     if (!strcmp(key, "act_q16") && (value == 0 || value == 1)) { g_act_q16 = value; return TEDM_OK; }

@@ -546,6 +546,30 @@ def test_linattn_own_layernorm_statistics(lib, dev):
             assert rel(a_, b_) < EPS_GATE / 2
 
 
+@pytest.mark.parametrize('prec', ['bf16x3', 'f16f4'])
+def test_final_block_tail_folded_with_final_conv(lib, dev, prec):
+    """Inference folds final_res_block's res_conv + silu(GN2) with final_conv into one fp32 elementwise pass (both 1x1 convolutions
+    are linear: eps = (Wf W_res) . cat + Wf . silu(a y2 + b) + const; elementwise.hip: final_fused_kernel) -- against the
+    unfolded kernels; 96x72 exercises ragged tiles.  (TEDM_FWD_TRACE runs unfolded: the oracle trace tests cover that path.)"""
+    from tedm_amd import _lib
+    m = make_unet(64, 0, dev, prec)
+    g = torch.Generator().manual_seed(23)
+    for shape in ((2, 1, 64, 64), (1, 1, 96, 72)):
+        x, t = torch.randn(*shape, generator=g).to(dev), torch.randint(0, 1000, (shape[0],), generator=g).to(dev)
+        res = {}
+        try:
+            for mode in (1, 0):
+                _lib.check(lib.tedm_set_tuning(b'final_fuse', mode), 'tune')
+                with torch.no_grad():
+                    res[mode] = m.native_forward(x, t)
+        finally:
+            lib.tedm_set_tuning(b'final_fuse', 1)
+        e1, e0 = (r[0] if isinstance(r, (tuple, list)) else r for r in (res[1], res[0]))
+        assert torch.isfinite(e1).all()
+        assert rel(e1, e0) < (1e-4 if prec == 'bf16x3' else EPS_GATE / 2)
+        assert not torch.equal(e1, e0)
+
+
 def test_vs_oracle_ragged_shape(dev, unet64):
     """B=3, 96x72 (not a power of two, H != W) against the oracle incl. module trace."""
     from oracle import unet_ref as O
