@@ -28,4 +28,6 @@ rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- pytho
 python tools/trace_one_step.py gpurun_out/${tag}_trace > profiles/${tag}_step_timeline.txt
 # eps error over seeds / timesteps against the CPU oracle (test infrastructure)
 python tests/eps_margin.py 4 2>/dev/null > profiles/${tag}_eps_margin.txt
-echo "profiles/${tag}_* written"
+# gpurun merges only gpurun_out/ back: leave a copy there (copy it into profiles/ after the call)
+mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* gpurun_out/profiles_${tag}/
+echo "profiles/${tag}_* written (copy under gpurun_out/profiles_${tag}/)"
