@@ -53,6 +53,21 @@ namespace ns {
 #undef CONV_LAB_NOSCALE
 
 static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
+namespace d1 {
+#define CONV_LAB_DELAY 16
+#include "conv_igemm.inc"
+#undef CONV_LAB_DELAY
+}
+namespace d2 {
+#define CONV_LAB_DELAY 32
+#include "conv_igemm.inc"
+#undef CONV_LAB_DELAY
+}
+namespace d3 {
+#define CONV_LAB_DELAY 64
+#include "conv_igemm.inc"
+#undef CONV_LAB_DELAY
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 struct Shape { const char* name; int C1, C2, Cout, S, gn; int k = 3; };
@@ -173,6 +188,11 @@ int main(int argc, char** argv) {
     else if (sh.Cout < 256) { RUNT(v0, 2, 4, 4, PRO, 1, "2x4 mt4 (product)"); RUNT(v0, 1, 4, 8, PRO, 1, "1x4 mt8"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); } \
     else                    { RUNT(v0, 1, 8, 4, PRO, 1, "1x8 mt4 (product)"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); }
             if (sh.gn) { TILES(1) } else { TILES(0) }
+#elif defined(LAB_PHASE)   // two independent 4-wave workgroups per CU (2x2 tile), the one in the odd wave slot started late
+            if (sh.Cout < 128) {
+#define PH(PRO) RUNT(v0, 2, 2, 4, PRO, 4, "2x2 product"); RUNT(d1, 2, 2, 4, PRO, 4, "2x2 odd slot +1k cycles"); RUNT(d2, 2, 2, 4, PRO, 4, "2x2 odd slot +2k cycles"); RUNT(d3, 2, 2, 4, PRO, 4, "2x2 odd slot +4k cycles")
+                if (sh.gn) { PH(1); } else { PH(0); }
+            }
 #else
             if (sh.Cout < 128) {
                 if (sh.gn) { ALLV(2, 2, 4, 1, 4, "narrow"); } else { ALLV(2, 2, 4, 0, 4, "narrow"); }
