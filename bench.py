@@ -66,9 +66,14 @@ def pmc_traffic(kernel: str):
     if not files:
         return None
     try:
-        return json.loads(files[-1].read_text())['kernels'][kernel]['hbm_bytes_per_launch']
+        ks = json.loads(files[-1].read_text())['kernels']
     except Exception:
         return None
+    # rocprof prints every template argument; the library's label omits the trailing QIO = 0 of conv_igemm_kernel
+    for name in (kernel, kernel[:-1] + ',0>' if kernel.endswith('>') else kernel):
+        if name in ks:
+            return ks[name].get('hbm_bytes_per_launch')
+    return None
 
 
 def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):

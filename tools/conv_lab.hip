@@ -53,6 +53,30 @@ namespace ns {
 #undef CONV_LAB_NOSCALE
 
 static size_t conv_packed_bytes_lab(int Cout, int Cin, int taps) { return (size_t)((Cout + 31) / 32) * (Cin / 16) * taps * 2 * 1024; }
+#ifdef LAB_PREFETCH    // prefetch policy of the single-fp16-product / f16f4 instances on the 8-row tile (-DLAB_PREFETCH)
+namespace p0 {
+#define CONV_LAB_PD 0
+#include "conv_igemm.inc"
+#undef CONV_LAB_PD
+}
+namespace p2 {
+#define CONV_LAB_PD 2
+#include "conv_igemm.inc"
+#undef CONV_LAB_PD
+}
+namespace s0 {
+#define CONV_LAB_SPREAD 0
+#include "conv_igemm.inc"
+#undef CONV_LAB_SPREAD
+}
+namespace p2s0 {
+#define CONV_LAB_PD 2
+#define CONV_LAB_SPREAD 0
+#include "conv_igemm.inc"
+#undef CONV_LAB_SPREAD
+#undef CONV_LAB_PD
+}
+#endif
 namespace d1 {
 #define CONV_LAB_DELAY 16
 #include "conv_igemm.inc"
@@ -188,6 +212,16 @@ int main(int argc, char** argv) {
     else if (sh.Cout < 256) { RUNT(v0, 2, 4, 4, PRO, 1, "2x4 mt4 (product)"); RUNT(v0, 1, 4, 8, PRO, 1, "1x4 mt8"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); } \
     else                    { RUNT(v0, 1, 8, 4, PRO, 1, "1x8 mt4 (product)"); RUNT(v0, 1, 8, 8, PRO, 1, "1x8 mt8"); }
             if (sh.gn) { TILES(1) } else { TILES(0) }
+#elif defined(LAB_PREFETCH)
+#if LAB_PREC == 3   // (the rolling weight prefetch of f16f4 fixes the distance: only the staging policy varies)
+#define PFV(WM, WN, MT, PRO, TPW) RUNT(v0, WM, WN, MT, PRO, TPW, "product"); RUNT(s0, WM, WN, MT, PRO, TPW, "staging at one point")
+#else
+#define PFV(WM, WN, MT, PRO, TPW) RUNT(v0, WM, WN, MT, PRO, TPW, "product"); RUNT(p0, WM, WN, MT, PRO, TPW, "weights just in time"); \
+    RUNT(p2, WM, WN, MT, PRO, TPW, "weights two columns ahead"); RUNT(s0, WM, WN, MT, PRO, TPW, "staging at one point"); RUNT(p2s0, WM, WN, MT, PRO, TPW, "two ahead + one point")
+#endif
+            if (sh.Cout >= 256) { if (sh.gn) { PFV(1, 8, 8, 1, 1); } else { PFV(1, 8, 8, 0, 1); } }
+            else if (sh.Cout >= 128) { if (sh.gn) { PFV(2, 4, 4, 1, 1); } else { PFV(2, 4, 4, 0, 1); } }
+            else { if (sh.gn) { PFV(4, 2, 4, 1, 4); } else { PFV(4, 2, 4, 0, 4); } }
 #elif defined(LAB_PHASE)   // two independent 4-wave workgroups per CU (2x2 tile), the one in the odd wave slot started late
             if (sh.Cout < 128) {
 #define PH(PRO) RUNT(v0, 2, 2, 4, PRO, 4, "2x2 product"); RUNT(d1, 2, 2, 4, PRO, 4, "2x2 odd slot +1k cycles"); RUNT(d2, 2, 2, 4, PRO, 4, "2x2 odd slot +2k cycles"); RUNT(d3, 2, 2, 4, PRO, 4, "2x2 odd slot +4k cycles")
