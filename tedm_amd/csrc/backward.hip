@@ -31,21 +31,30 @@ __global__ void pool2x2_sum_kernel(const float* __restrict__ g, float* __restric
 // Pixel-classifier head, first layer applied at the taps' native resolution:
 //   out[n][y][x][:] = bias + sum_i z_i[n][y*h_i/S][x*w_i/S][:]      (nearest upsample of every projected tap + sum)
 struct UpSumArgs { const float* z[8]; int h[8]; int w[8]; int n; };
-__global__ void upsample_sum_kernel(UpSumArgs a, const float* __restrict__ bias, float* __restrict__ out, int B, int S, int C,
-                                    long long total4) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % (C / 4)) * 4;
-        long long r = i / (C / 4);
-        const int x = (int)(r % S); r /= S;
-        const int y = (int)(r % S);
-        const int n = (int)(r / S);
-        float4 s = bias ? *(const float4*)(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < a.n; ++k) {
-            const int sy = (int)((long long)y * a.h[k] / S), sx = (int)((long long)x * a.w[k] / S);   // F.interpolate 'nearest'
-            const float4 v = *(const float4*)(a.z[k] + (((size_t)n * a.h[k] + sy) * a.w[k] + sx) * C + c4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// One block row per image row: n, y and the source rows are block-uniform; per thread only 32-bit index arithmetic.
+__global__ __launch_bounds__(256) void upsample_sum_kernel(UpSumArgs a, const float* __restrict__ bias, float* __restrict__ out, int B, int S, int C,
+                                                           long long total4) {
+    (void)total4;
+    const int C4 = C >> 2, row4 = S * C4;                       // float4 per image row
+    for (int row = blockIdx.y; row < B * S; row += gridDim.y) {
+        const int n = row / S, y = row - n * S;
+        const float* zr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < a.n) zr[k] = a.z[k] + ((size_t)n * a.h[k] + (int)((long long)y * a.h[k] / S)) * a.w[k] * C;   // F.interpolate 'nearest'
+        float* orow = out + (size_t)row * S * C;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < row4; e += gridDim.x * 256) {
+            const int x = e / C4, c4 = (e - x * C4) * 4;
+            float4 s = bias ? *(const float4*)(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < a.n) {
+                    const int sx = (int)((unsigned)x * (unsigned)a.w[k] / (unsigned)S);
+                    const float4 v = *(const float4*)(zr[k] + (size_t)sx * C + c4);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            *(float4*)(orow + (size_t)e * 4) = s;
         }
-        *(float4*)(out + (size_t)i * 4) = s;
     }
 }
 // Inference-mode tail of the pixel classifier in ONE pass (models/datasetDM_model.py:57-64 after the first conv; eval-mode
@@ -101,20 +110,22 @@ __global__ __launch_bounds__(256) void head_tail_kernel(UpSumArgs a, const float
 }
 
 // its adjoint: out[n][y][x][:] = sum over the f x f block of g that nearest-upsampling maps to (y,x)   (S = f*h)
-__global__ void pool_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int h, int w, int f, int C, long long total4) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % (C / 4)) * 4;
-        long long r = i / (C / 4);
-        const int x = (int)(r % w); r /= w;
-        const int y = (int)(r % h);
-        const int n = (int)(r / h);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int dy = 0; dy < f; ++dy)
-            for (int dx = 0; dx < f; ++dx) {
-                const float4 v = *(const float4*)(g + (((size_t)n * h * f + y * f + dy) * w * f + x * f + dx) * C + c4);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-        *(float4*)(out + (size_t)i * 4) = s;
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int h, int w, int f, int C, long long total4) {
+    (void)total4;
+    const int C4 = C >> 2, row4 = w * C4;                       // float4 per output row; n, y block-uniform
+    for (int row = blockIdx.y; row < B * h; row += gridDim.y) {
+        const float* grow = g + (size_t)row * f * ((size_t)w * f) * C;          // (n * h + y) * f = first source row
+        float* orow = out + (size_t)row * w * C;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < row4; e += gridDim.x * 256) {
+            const int x = e / C4, c4 = (e - x * C4) * 4;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int dy = 0; dy < f; ++dy)
+                for (int dx = 0; dx < f; ++dx) {
+                    const float4 v = *(const float4*)(grow + ((size_t)dy * w * f + (size_t)x * f + dx) * C + c4);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            *(float4*)(orow + (size_t)e * 4) = s;
+        }
     }
 }
 
@@ -898,9 +909,11 @@ int op_upsample_sum(const float* const* z, const int* h, const int* w, int n, in
     a.n = n;
     for (int k = 0; k < n; ++k) { a.z[k] = z[k]; a.h[k] = h[k]; a.w[k] = w[k]; }
     const long long total4 = (long long)B * S * S * (C / 4);
-    long long blocks = (total4 + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(upsample_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, bias, out, B, S, C, total4);
+    if ((long long)B * S >= (1ll << 31) || (long long)S * (C / 4) >= (1ll << 31)) return TEDM_EINVAL;
+    const int bx = (S * (C / 4) + 255) / 256;
+    const int gx = bx > 64 ? 64 : bx, gy_cap = 16384 / gx;                     // ~16 k blocks, each walking several rows
+    dim3 grid(gx, (unsigned)((long long)B * S > gy_cap ? gy_cap : B * S));
+    hipLaunchKernelGGL(upsample_sum_kernel, grid, dim3(256), 0, st, a, bias, out, B, S, C, total4);
     return LAUNCH_OK();
 }
 int op_head_tail(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1, const float* w2t,
@@ -916,9 +929,11 @@ int op_head_tail(const float* const* z, const int* h, const int* w, int n, int B
 int op_pool_sum(const float* g, float* out, int B, int h, int w, int f, int C, hipStream_t st) {
     if (C % 4 || f < 1) return TEDM_EINVAL;
     const long long total4 = (long long)B * h * w * (C / 4);
-    long long blocks = (total4 + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(pool_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, out, B, h, w, f, C, total4);
+    if ((long long)B * h >= (1ll << 31) || (long long)w * (C / 4) >= (1ll << 31)) return TEDM_EINVAL;
+    const int bx = (w * (C / 4) + 255) / 256;
+    const int gx = bx > 64 ? 64 : bx, gy_cap = 16384 / gx;
+    dim3 grid(gx, (unsigned)((long long)B * h > gy_cap ? gy_cap : B * h));
+    hipLaunchKernelGGL(pool_sum_kernel, grid, dim3(256), 0, st, g, out, B, h, w, f, C, total4);
     return LAUNCH_OK();
 }
 int op_pool2x2_sum(const float* g, float* out, int B, int h, int w, int C, hipStream_t st) {

@@ -100,16 +100,21 @@ class FusedFirstLayer(torch.autograd.Function):
         dW = torch.empty(Cout, sum(t.shape[3] for t in taps), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _stream(dev)
-            dz = []
+            # block sums of dh1 per tap resolution, as a cascade: a coarser level pools the next finer one that divides it (one read
+            # of the full-resolution gradient instead of one per level)
+            pooled = {1: g}
             for i in range(n_taps):
                 _, h, w, _ = taps[i].shape
-                if h == S and w == S:
-                    dz.append(g)
+                assert S % h == 0 and S % w == 0 and S // h == S // w, 'taps must be integer down-scalings of the image'
+            for f in sorted({S // taps[i].shape[1] for i in range(n_taps)}):
+                if f in pooled:
                     continue
-                assert S % h == 0 and S // h == S // w, 'taps must be integer down-scalings of the image'
-                d = torch.empty(B, h, w, Cout, dtype=torch.float32, device=dev)
-                _lib.check(L.tedm_pool_sum_nhwc(g.data_ptr(), B, h, w, S // h, Cout, d.data_ptr(), st), 'tedm_pool_sum_nhwc')
-                dz.append(d)
+                base = max(k for k in pooled if f % k == 0)
+                src = pooled[base]
+                d = torch.empty(B, S // f, S // f, Cout, dtype=torch.float32, device=dev)
+                _lib.check(L.tedm_pool_sum_nhwc(src.data_ptr(), B, S // f, S // f, f // base, Cout, d.data_ptr(), st), 'tedm_pool_sum_nhwc')
+                pooled[f] = d
+            dz = [pooled[S // taps[i].shape[1]] for i in range(n_taps)]
             off = 0
             for k, tap in enumerate(taps):
                 i = k % n_taps
