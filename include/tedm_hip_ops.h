@@ -90,8 +90,12 @@ int tedm_op_linattn_fused(const float* x, int C, const float* g, const float* ln
 
 /* Tuning knobs (benchmark harness / A-B tests; defaults are the product's): "conv_tile_wide", "conv_tile_wide256",
  * "conv_tile_narrow" (workgroup tile per output-channel range), "conv_tpw_max", "conv_xcd_order", "conv_prio", "conv_solo"
- * (conv_igemm.hip); "conv_up_split" 0|1 (Upsample as parity convolutions), "la_fused" 0|1|2, "la_tail" 0|1 (linear-attention
- * sweeps, unet_host.hip); "deep_fp16" 0|1|2 (which convolutions run one fp16 product under TEDM_PREC_F16F4: none | the 3x3 convs
+ * (conv_igemm.hip; tile ids 0-6, of which 5 = 1x8 waves x 8 rows and 6 = 4x2 waves are the defaults for Cout >= 256 / Cout < 128;
+ * every tile gives the same bits), "conv_small_grid" 0|1 (smaller tiles for launches of < 256 workgroups); "conv_up_split" 0|1
+ * (Upsample as parity convolutions), "la_fused" 0|1|2, "la_tail" 0|1, "la_ctx_one" 0|1 (context sweep at C = 64 behind one barrier
+ * per tile), "la_self_ln" 0|1 (the fused linear-attention kernels compute the PreNorm statistics themselves where they can),
+ * "final_fuse" 0|1 (final_res_block's tail folded with final_conv; inference), "act_q16" / "act_q16_max_c" (Q16 branch storage,
+ * off) (unet_host.hip, linattn_fused.hip); "deep_fp16" 0|1|2 (which convolutions run one fp16 product under TEDM_PREC_F16F4: none | the 3x3 convs
  * inside the ResnetBlocks below full resolution (default) | every k x k conv with >= 256 output channels; read by tedm_unet_pack,
  * so set it before packing); wgrad keys (wgrad.hip).  Unknown keys / values return TEDM_EINVAL. */
 int tedm_set_tuning(const char* key, int value);
