@@ -206,6 +206,22 @@ int tedm_upsample_sum_nhwc(const float* const* z, const int* h, const int* w, in
  * 32-channel tensor reaches HBM.  All pointers device; b3: 1 float. */
 int tedm_head_tail_nhwc(const float* const* z, const int* h, const int* w, int n, int B, int S, int C1, const float* b1,
                         const float* w2t, const float* b2, const float* w3, const float* b3, float* logits, void* stream);
+/* TRAINING-mode tail of the classifier behind its first conv (models/datasetDM_model.py:59-64: ReLU, BatchNorm2d(C1), Conv2d(C1,32,1),
+ * ReLU, BatchNorm2d(32), Conv2d(32,1,1)) on h1 (P pixels x C1, NHWC) in three forward and three backward passes; only z2 (P x 32) is
+ * kept, everything else is recomputed (tedm_amd/csrc/head_train.hip; tedm_amd/head.py derives the coefficient vectors between the
+ * passes).  `blocks` = number of per-block partial results the caller allocated = workgroups launched; partials are summed by the
+ * caller in a fixed order (deterministic).  a / b: BatchNorm as y = a x + b; k [3][32], m [3][C1]: coefficients of
+ * dz2 = [z2 > 0] (k0 dl + k1 + k2 z2) and dh1 = [h1 > 0] (m0 du + m1 + m2 h1), du = W2^T dz2. */
+int tedm_head_train_stats1(const float* h1, long long P, int C1, float* part /*[blocks][C1][2]*/, int blocks, void* stream);
+int tedm_head_train_mid(const float* h1, long long P, int C1, const float* a1, const float* b1, const float* w2t /*[C1][32]*/,
+                        const float* bias2, float* z2 /*[P][32]*/, float* part2 /*[blocks][32][2]*/, int blocks, void* stream);
+int tedm_head_train_out(const float* z2, long long P, const float* a2, const float* b2, const float* w3, const float* b3,
+                        float* logits /*[P]*/, void* stream);
+int tedm_head_train_bwd1(const float* z2, const float* dl, long long P, float* part /*[blocks][33]: A1[32], A0*/, int blocks, void* stream);
+int tedm_head_train_bwd2(const float* h1, const float* z2, const float* dl, long long P, int C1 /*128 | 256*/, const float* k,
+                         float* part /*[blocks][32*C1 + 32]: G[32][C1], db2[32]*/, int blocks, void* stream);
+int tedm_head_train_bwd3(const float* h1, const float* z2, const float* dl, long long P, int C1, const float* k, const float* w2 /*[32][C1]*/,
+                         const float* m, float* dh1, void* stream);
 /* adjoint of one nearest upsample by `factor`: out (B,h,w,C) = block sums of g (B,h*factor,w*factor,C). */
 int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, float* out, void* stream);
 

@@ -65,6 +65,12 @@ _SIGNATURES = {
     'tedm_upsample_sum_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'tedm_pool_sum_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'tedm_head_tail_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    'tedm_head_train_stats1': (C.c_int, [_P, C.c_longlong, C.c_int, _P, C.c_int, _P]),
+    'tedm_head_train_mid': (C.c_int, [_P, C.c_longlong, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    'tedm_head_train_out': (C.c_int, [_P, C.c_longlong, _P, _P, _P, _P, _P, _P]),
+    'tedm_head_train_bwd1': (C.c_int, [_P, _P, C.c_longlong, _P, C.c_int, _P]),
+    'tedm_head_train_bwd2': (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_int, _P]),
+    'tedm_head_train_bwd3': (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, _P, _P, _P]),
     'tedm_unet_trace_count': (C.c_int, [_P]),
     'tedm_unet_trace_name': (C.c_char_p, [_P, C.c_int]),
     'tedm_unet_trace_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

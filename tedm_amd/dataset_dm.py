@@ -168,7 +168,7 @@ class DatasetDM(nn.Module):
         layout = self.head_layout() if self.fused_head else None
         if layout is None:
             return self.classifier(self.extract_features(x, noise=noise).to(x.device))
-        from .head import eval_tail_supported, fused_first_layer, fused_head_eval
+        from .head import eval_tail_supported, fused_first_layer, fused_head_eval, fused_tail_train, train_tail_supported
         kind, ci = layout
         unet = self.diffusion_model.model                       # the head trains at the UNet's training precision
         prec = unet.train_precision if (torch.is_grad_enabled() and self.training) else unet.precision
@@ -178,4 +178,7 @@ class DatasetDM(nn.Module):
             # inference: up-sampling sum, ReLU, both folded BatchNorms and the 128 -> 32 -> 1 layers in ONE kernel after the projections
             return fused_head_eval(conv, tail, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
         h1 = fused_first_layer(conv, taps, x.shape[-1], _lib.PREC_BY_NAME[prec])
+        if self.fused_tail and self.training and torch.is_grad_enabled() and train_tail_supported(tail, conv.out_channels):
+            # training: the tail's ~15 torch tensor passes as three forward and three backward kernels (csrc/head_train.hip)
+            return fused_tail_train(tail, h1)
         return self.classifier[ci + 1:](h1)

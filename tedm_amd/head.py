@@ -198,3 +198,131 @@ def fused_head_eval(conv: torch.nn.Conv2d, tail: Sequence[torch.nn.Module], taps
         _lib.check(L.tedm_head_tail_nhwc(zp, hh, ww, n_taps, B, S, c1, b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), w3f.data_ptr(),
                                          b3.data_ptr(), logits.data_ptr(), st), 'tedm_head_tail_nhwc')
     return logits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training-mode tail (ReLU, BatchNorm2d, Conv2d(c1, 32, 1), ReLU, BatchNorm2d, Conv2d(32, 1, 1)) in three forward and three
+# backward passes over h1 (tedm_amd/csrc/head_train.hip).  torch runs it as ~15 tensor passes.
+
+def train_tail_supported(tail: Sequence[torch.nn.Module], c1: int) -> bool:
+    """True when `tail` is exactly the reference's classifier tail (models/datasetDM_model.py:59-64) in TRAINING mode with affine,
+    running-statistics BatchNorms and a numeric momentum, and c1 is a width the kernels are built for."""
+    nn = torch.nn
+    if len(tail) != 6 or c1 not in (128, 256):
+        return False
+    r1, bn1, c2, r2, bn2, c3 = tail
+    ok = (isinstance(r1, nn.ReLU) and isinstance(r2, nn.ReLU) and isinstance(bn1, nn.BatchNorm2d) and isinstance(bn2, nn.BatchNorm2d)
+          and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d))
+    if not ok:
+        return False
+    for bn, n in ((bn1, c1), (bn2, 32)):
+        if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.num_features == n):
+            return False
+    return (c2.kernel_size == (1, 1) and c2.in_channels == c1 and c2.out_channels == 32 and c2.groups == 1 and c2.bias is not None
+            and c3.kernel_size == (1, 1) and c3.in_channels == 32 and c3.out_channels == 1 and c3.bias is not None)
+
+
+def _bn_coeffs(part: Tensor, P: int, gamma: Tensor, beta: Tensor, eps: float):
+    """Per-block (sum, sumsq) partials [blocks][C][2] -> batch mean, biased variance, rstd and y = a x + b (fp64 reduction)."""
+    s = part.double().sum(0)
+    mean = s[:, 0] / P
+    var = (s[:, 1] / P - mean * mean).clamp_min(0.0)
+    rstd = torch.rsqrt(var + eps)
+    a = gamma.double() * rstd
+    b = beta.double() - mean * a
+    return mean, var, rstd, a.float().contiguous(), b.float().contiguous()
+
+
+class FusedTailTrain(torch.autograd.Function):
+    """logits (B, 1, S, S) = tail(h1) for h1 given as the NHWC-contiguous (B, S, S, C1) buffer; returns also the batch statistics
+    (mean1, var1, mean2, var2: biased) for the caller's running-statistics update."""
+
+    BLOCKS = 1024
+
+    @staticmethod
+    def forward(ctx, h1: Tensor, g1, be1, w2, bias2, g2, be2, w3, b3, eps1: float, eps2: float):
+        L = _lib.lib()
+        dev = h1.device
+        assert h1.is_contiguous() and h1.dtype == torch.float32 and h1.dim() == 4
+        B, S, S2, C1 = h1.shape
+        P = B * S * S2
+        nb = FusedTailTrain.BLOCKS
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            part1 = torch.empty(nb, C1, 2, **f32)
+            _lib.check(L.tedm_head_train_stats1(h1.data_ptr(), P, C1, part1.data_ptr(), nb, st), 'tedm_head_train_stats1')
+            mean1, var1, rstd1, a1, b1 = _bn_coeffs(part1, P, g1.detach(), be1.detach(), eps1)
+            w2m = w2.detach().reshape(32, C1).float().contiguous()
+            w2t = w2m.t().contiguous()
+            z2 = torch.empty(P, 32, **f32)
+            part2 = torch.empty(nb, 32, 2, **f32)
+            _lib.check(L.tedm_head_train_mid(h1.data_ptr(), P, C1, a1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                             bias2.detach().float().contiguous().data_ptr(), z2.data_ptr(), part2.data_ptr(), nb, st),
+                       'tedm_head_train_mid')
+            mean2, var2, rstd2, a2, b2 = _bn_coeffs(part2, P, g2.detach(), be2.detach(), eps2)
+            w3v = w3.detach().reshape(32).float().contiguous()
+            logits = torch.empty(B, 1, S, S2, **f32)
+            _lib.check(L.tedm_head_train_out(z2.data_ptr(), P, a2.data_ptr(), b2.data_ptr(), w3v.data_ptr(),
+                                             b3.detach().float().contiguous().data_ptr(), logits.data_ptr(), st), 'tedm_head_train_out')
+        ctx.save_for_backward(h1, z2, a1, b1, a2, b2, w2m, w3v, mean1, rstd1, mean2, rstd2)
+        ctx.meta = (P, C1, tuple(w2.shape), tuple(w3.shape))
+        ctx.mark_non_differentiable(mean1, var1, mean2, var2)
+        return logits, mean1, var1, mean2, var2
+
+    @staticmethod
+    def backward(ctx, dlogits: Tensor, *_unused):
+        L = _lib.lib()
+        h1, z2, a1, b1, a2, b2, w2m, w3v, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        P, C1, w2shape, w3shape = ctx.meta
+        dev = h1.device
+        nb = FusedTailTrain.BLOCKS
+        f32 = dict(dtype=torch.float32, device=dev)
+        dl = dlogits.reshape(-1).float().contiguous()
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            pa = torch.empty(nb, 33, **f32)
+            _lib.check(L.tedm_head_train_bwd1(z2.data_ptr(), dl.data_ptr(), P, pa.data_ptr(), nb, st), 'tedm_head_train_bwd1')
+            A = pa.double().sum(0)
+            A1, A0 = A[:32], A[32]
+            a2d, b2d, w3d = a2.double(), b2.double(), w3v.double()
+            db3 = A0.reshape(1)
+            dW3 = a2d * A1 + b2d * A0
+            S1 = w3d * A0                                         # dbeta2
+            S2 = w3d * (A1 - mean2 * A0) * rstd2                  # dgamma2
+            k = torch.stack((a2d * w3d, -a2d * S1 / P + a2d * rstd2 * mean2 * S2 / P, -a2d * rstd2 * S2 / P)).float().contiguous()
+            pg = torch.empty(nb, 32 * C1 + 32, **f32)
+            _lib.check(L.tedm_head_train_bwd2(h1.data_ptr(), z2.data_ptr(), dl.data_ptr(), P, C1, k.data_ptr(), pg.data_ptr(), nb, st),
+                       'tedm_head_train_bwd2')
+            G = pg.double().sum(0)
+            db2 = G[32 * C1:]
+            G = G[:32 * C1].reshape(32, C1)
+            a1d, b1d, w2d = a1.double(), b1.double(), w2m.double()
+            dW2 = a1d[None, :] * G + b1d[None, :] * db2[:, None]
+            T1 = (w2d * db2[:, None]).sum(0)                                       # dbeta1
+            T2 = (w2d * (G - mean1[None, :] * db2[:, None])).sum(0) * rstd1        # dgamma1
+            m = torch.stack((a1d, -a1d * T1 / P + a1d * rstd1 * mean1 * T2 / P, -a1d * rstd1 * T2 / P)).float().contiguous()
+            dh1 = torch.empty_like(h1)
+            _lib.check(L.tedm_head_train_bwd3(h1.data_ptr(), z2.data_ptr(), dl.data_ptr(), P, C1, k.data_ptr(), w2m.data_ptr(), m.data_ptr(),
+                                              dh1.data_ptr(), st), 'tedm_head_train_bwd3')
+        return (dh1, T2.float(), T1.float(), dW2.float().reshape(w2shape), db2.float(), S2.float(), S1.float(),
+                dW3.float().reshape(w3shape), db3.float(), None, None)
+
+
+def fused_tail_train(tail: Sequence[torch.nn.Module], h1_nchw: Tensor) -> Tensor:
+    """tail(h1) in training mode through FusedTailTrain, including the BatchNorm running-statistics update (momentum rule and
+    unbiased running variance of nn.BatchNorm2d).  h1_nchw: the (B, C1, S, S) channels-last VIEW FusedFirstLayer returns."""
+    _, bn1, c2, _, bn2, c3 = tail
+    h1 = h1_nchw.permute(0, 2, 3, 1)
+    if not h1.is_contiguous():
+        h1 = h1.contiguous()
+    logits, mean1, var1, mean2, var2 = FusedTailTrain.apply(h1, bn1.weight, bn1.bias, c2.weight, c2.bias, bn2.weight, bn2.bias,
+                                                            c3.weight, c3.bias, bn1.eps, bn2.eps)
+    P = h1.shape[0] * h1.shape[1] * h1.shape[2]
+    with torch.no_grad():
+        for bn, mean, var in ((bn1, mean1, var1), (bn2, mean2, var2)):
+            mom = bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (P / max(P - 1, 1))).to(bn.running_var.dtype), alpha=mom)
+            bn.num_batches_tracked += 1
+    return logits

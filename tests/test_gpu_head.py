@@ -68,3 +68,49 @@ def test_fused_head_gradients_match_unfused_autograd(dev, golden_dir):
         if k != 'loss':
             assert rel(grads[True][k], grads[False][k]) < 2e-3, (k, rel(grads[True][k], grads[False][k]))
     assert all(p.grad is None for p in dm.diffusion_model.parameters())           # the diffusion model stays frozen
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 128), (1, 40, 256), (3, 16, 128)], ids=['B2_S24_C128', 'B1_S40_C256', 'B3_S16_C128'])
+def test_fused_training_tail_matches_torch_modules(dev, shape):
+    """tedm_amd/csrc/head_train.hip (three forward + three backward passes, BatchNorm batch statistics and backward sums derived
+    between them) against the reference's own torch layers (models/datasetDM_model.py:59-64) in training mode: logits, the gradient
+    of the input, every parameter gradient and the running-statistics update.  Pixel counts that are no multiple of the 256- / 64-pixel
+    tiles exercise the masked tails."""
+    from tedm_amd.head import fused_tail_train, train_tail_supported
+    B, S, C1 = shape
+    nn = torch.nn
+    g = torch.Generator().manual_seed(7)
+
+    def make():
+        torch.manual_seed(3)
+        tail = nn.Sequential(nn.ReLU(), nn.BatchNorm2d(C1), nn.Conv2d(C1, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1))
+        with torch.no_grad():
+            for bn in (tail[1], tail[4]):
+                bn.weight.copy_(1 + 0.2 * torch.randn(bn.num_features))
+                bn.bias.copy_(0.1 * torch.randn(bn.num_features))
+        return tail.to(dev).train()
+
+    h_nhwc = (torch.randn(B, S, S, C1, generator=g) * 1.5 + 0.3).to(dev)
+    dlog = torch.randn(B, 1, S, S, generator=g).to(dev) / (B * S * S)
+    res = {}
+    for kind in ('torch', 'fused'):
+        tail = make()
+        h = h_nhwc.clone().requires_grad_(True)
+        h_nchw = h.permute(0, 3, 1, 2)                       # the channels-last view FusedFirstLayer hands over
+        if kind == 'fused':
+            assert train_tail_supported(list(tail), C1)
+            out = fused_tail_train(list(tail), h_nchw)
+        else:
+            out = tail(h_nchw)
+        out.backward(dlog)
+        res[kind] = dict(out=out.detach().double(), dh=h.grad.double(),
+                         grads={k: p.grad.double() for k, p in tail.named_parameters()},
+                         bufs={k: b.detach().double() for k, b in tail.named_buffers()})
+    rl = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    t, f = res['torch'], res['fused']
+    assert rl(f['out'], t['out']) < 2e-5
+    assert rl(f['dh'], t['dh']) < 2e-4
+    for k in t['grads']:
+        assert rl(f['grads'][k], t['grads'][k]) < 5e-4, k
+    for k in t['bufs']:
+        assert rl(f['bufs'][k], t['bufs'][k]) < 1e-5, k

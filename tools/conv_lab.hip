@@ -159,7 +159,7 @@ int main(int argc, char** argv) {
     const char* only = argc > 3 ? argv[3] : nullptr;            // run just this shape (profiling)
     const Shape shapes[] = {
         {"l0_64_64", 64, 0, 64, 256, 0}, {"l0_64_64_gn", 64, 0, 64, 256, 1}, {"l0_128_64", 64, 64, 64, 256, 0},
-        {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l2_384_256", 256, 128, 256, 64, 0},
+        {"l1_128_128_gn", 128, 0, 128, 128, 1}, {"l1_192_128", 128, 64, 128, 128, 0}, {"l2_128_128_gn", 128, 0, 128, 64, 1}, {"l2_256_256_gn", 256, 0, 256, 64, 1}, {"l2_384_256", 256, 128, 256, 64, 0},
         {"l3_512_512_gn", 512, 0, 512, 32, 1}, {"l3_768_512", 512, 256, 512, 32, 0},
         {"res_768_512", 512, 256, 512, 32, 0, 1}, {"res_384_256", 256, 128, 256, 64, 0, 1}, {"res_192_128", 128, 64, 128, 128, 0, 1},
         {"res_128_64", 64, 64, 64, 256, 0, 1},
@@ -220,7 +220,10 @@ int main(int argc, char** argv) {
     RUNT(p2, WM, WN, MT, PRO, TPW, "weights two columns ahead"); RUNT(s0, WM, WN, MT, PRO, TPW, "staging at one point"); RUNT(p2s0, WM, WN, MT, PRO, TPW, "two ahead + one point")
 #endif
             if (sh.Cout >= 256) { if (sh.gn) { PFV(1, 8, 8, 1, 1); } else { PFV(1, 8, 8, 0, 1); } }
-            else if (sh.Cout >= 128) { if (sh.gn) { PFV(2, 4, 4, 1, 1); } else { PFV(2, 4, 4, 0, 1); } }
+            else if (sh.Cout >= 128) {
+                if (sh.gn) { PFV(2, 4, 4, 1, 1); RUNT(v0, 2, 4, 8, 1, 1, "2x4x8 spread"); RUNT(s0, 2, 4, 8, 1, 1, "2x4x8 one point"); }
+                else { PFV(2, 4, 4, 0, 1); RUNT(v0, 2, 4, 8, 0, 1, "2x4x8 spread"); RUNT(s0, 2, 4, 8, 0, 1, "2x4x8 one point"); }
+            }
             else { if (sh.gn) { PFV(4, 2, 4, 1, 4); } else { PFV(4, 2, 4, 0, 4); } }
 #elif defined(LAB_PHASE)   // two independent 4-wave workgroups per CU (2x2 tile), the one in the odd wave slot started late
             if (sh.Cout < 128) {
