@@ -70,7 +70,8 @@ def test_fused_head_gradients_match_unfused_autograd(dev, golden_dir):
     assert all(p.grad is None for p in dm.diffusion_model.parameters())           # the diffusion model stays frozen
 
 
-@pytest.mark.parametrize('shape', [(2, 24, 128), (1, 40, 256), (3, 16, 128)], ids=['B2_S24_C128', 'B1_S40_C256', 'B3_S16_C128'])
+@pytest.mark.parametrize('shape', [(2, 24, 128), (1, 40, 256), (3, 16, 128), (1, 18, 128)],
+                         ids=['B2_S24_C128', 'B1_S40_C256', 'B3_S16_C128', 'B1_S18_C128_ragged64'])
 def test_fused_training_tail_matches_torch_modules(dev, shape):
     """tedm_amd/csrc/head_train.hip (three forward + three backward passes, BatchNorm batch statistics and backward sums derived
     between them) against the reference's own torch layers (models/datasetDM_model.py:59-64) in training mode: logits, the gradient
