@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for shape in ${PMC_SHAPES:-l0_64_64 l0_128_64}; do
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_WAIT_INST_VMEM GRBM_GUI_ACTIVE"; do
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_lab -- tools/build/conv_lab 3 1 $shape > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_lab -- ${PMC_BIN:-tools/build/conv_lab} 3 1 $shape > /dev/null 2>&1
   python3 - "$shape" <<'PY'
 import csv, glob, sys, collections
 f = sorted(glob.glob('gpurun_out/pmc_lab/**/*counter_collection.csv', recursive=True))
