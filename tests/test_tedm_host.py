@@ -166,3 +166,30 @@ def test_reference_written_checkpoint_loads(golden_dir):
     assert rel(eps, probe['eps']) < 1e-6
     with pytest.raises(FileNotFoundError):                             # not reported as an unpickling problem
         load_checkpoint(golden_dir / 'no_such_file.pt')
+
+
+def test_classifier_tail_kernel_dispatch_rules():
+    """tedm_amd/head.py: the HIP tail kernels take over exactly for the reference's classifier tail (models/datasetDM_model.py:59-64)
+    -- folded single kernel in eval mode, six-pass kernels in training mode -- and leave every other tail to the module's own layers."""
+    from torch import nn
+    from tedm_amd.head import eval_tail_supported, train_tail_supported
+
+    def tail(c1=128, mid=32, momentum=0.1, affine=True, track=True, bias=True):
+        return [nn.ReLU(), nn.BatchNorm2d(c1, momentum=momentum, affine=affine, track_running_stats=track), nn.Conv2d(c1, mid, 1, bias=bias),
+                nn.ReLU(), nn.BatchNorm2d(mid, momentum=momentum, affine=affine, track_running_stats=track), nn.Conv2d(mid, 1, 1, bias=bias)]
+
+    t = tail()
+    assert train_tail_supported(t, 128) and not eval_tail_supported(t, 128)              # fresh modules are in training mode
+    for m in t:
+        m.eval()
+    assert eval_tail_supported(t, 128) and not train_tail_supported(t, 128)
+    assert train_tail_supported(tail(256), 256)
+    assert not train_tail_supported(tail(64), 64)                     # width the gradient kernel is not built for -> torch layers
+    assert not train_tail_supported(tail(momentum=None), 128)         # cumulative-average BatchNorm: torch layers
+    assert not train_tail_supported(tail(affine=False), 128)
+    assert not train_tail_supported(tail(track=False), 128)
+    assert not train_tail_supported(tail(bias=False), 128)
+    assert not train_tail_supported(tail(mid=16), 128)
+    assert not train_tail_supported(tail()[:-1] + [nn.Conv2d(32, 2, 1)], 128)
+    assert not train_tail_supported(tail() + [nn.Sigmoid()], 128)
+    assert not train_tail_supported(tail(), 256)                      # first-layer width does not match the BatchNorm
