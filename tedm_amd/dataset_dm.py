@@ -41,7 +41,7 @@ class DatasetDM(nn.Module):
         feat_ch = sum(s[3] for s in self.diffusion_model.model._tap_shapes(1, 8, 8))   # 960 for the default UNet
         self.feature_channels = feat_ch
         self.fused_head = bool(getattr(args, 'fused_head', True))
-        self.fused_tail = bool(getattr(args, 'fused_tail', True))     # the rest of the head as HIP kernels: one under no_grad (head.fused_head_eval), six passes in training (head.FusedTailTrain)
+        self.fused_tail = bool(getattr(args, 'fused_tail', os.environ.get('TEDM_FUSED_TAIL', '1') != '0'))     # the rest of the head as HIP kernels: one under no_grad (head.fused_head_eval), six passes in training (head.FusedTailTrain)
         # TEDM (trainers/train_datasetDM.py:30-42): ONE classifier shared by all timesteps.  The reference swaps it in after
         # construction; both routes work here (`args.shared_weights_over_timesteps`, config.py, or assigning
         # `model.classifier = nn.Sequential(Rearrange(...), nn.Conv2d(960, 128, 1), ...)` later).
