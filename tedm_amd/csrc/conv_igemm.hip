@@ -11,6 +11,12 @@ int conv_launch_prec2(const ConvArgs& a, int KH, int stride, int ups, int pro, i
 int conv_launch_prec3(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
 int conv_launch_prec4(const ConvArgs& a, int KH, int stride, int ups, int pro, int tile_id, hipStream_t st);
 
+// conv_slide.hip: sliding-window kernel of the full-resolution 64-channel 3x3 convs (TEDM_PREC_F16F4)
+bool conv_slide_supported(const ConvArgs& a, int KH, int stride, int ups, int pro);
+int conv_slide_launch(const ConvArgs& a, int pro, hipStream_t st);
+void conv_slide_label(const ConvArgs& a, int pro, char* buf, int cap);
+extern int g_conv_slide, g_conv_slide_rows;
+
 int g_conv_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
 int g_conv_solo = 0;           // tedm_set_tuning("conv_solo", 1): pad the LDS request so that workgroups do not share a CU (diagnostic)
 int g_conv_tpw_max = 4;        // max spatial tiles per workgroup (tedm_set_tuning("conv_tpw_max", v))
@@ -94,11 +100,14 @@ int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_conv_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && ((v >= 0 && v <= 3) || v == 6)) { g_tile_narrow = v; return TEDM_OK; }
     if (!strcmp(key, "conv_small_grid") && (v == 0 || v == 1)) { g_conv_small_grid = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_slide") && (v == 0 || v == 1)) { g_conv_slide = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_slide_rows") && v >= 0 && v % 8 == 0) { g_conv_slide_rows = v; return TEDM_OK; }
     return TEDM_EINVAL;
 }
 
 // Label == the rocprof kernel symbol (template argument list of conv_igemm_kernel).
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
+    if (conv_slide_supported(a, KH, stride, ups, pro)) { conv_slide_label(a, pro, buf, cap); return; }
     const int id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
@@ -128,6 +137,7 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     const int Cin = a.C1 + a.C2;
     if (Cin % 16 || a.C1 % 16 || (a.x2 && a.C2 % 16)) return TEDM_EINVAL;
     if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
+    if (conv_slide_supported(a, KH, stride, ups, pro)) return conv_slide_launch(a, pro, st);
     const int tile_id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(tile_id, stride);
     const int TR = t.wm * t.mt;

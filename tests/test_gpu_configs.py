@@ -250,3 +250,32 @@ def test_sub_batches_on_two_streams_are_bit_identical(dev, prec):
         assert torch.equal(e3, e1[:17])
         small, _ = m.native_forward(x[:4], t[:4])               # below stream_min_batch: single stream
         assert torch.equal(small, e1[:4])
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'f16f4'])
+def test_reference_written_checkpoint_on_the_gpu(dev, golden_dir, prec):
+    """SURVEY 8 f4 on the HIP path: a checkpoint WRITTEN BY THE REFERENCE (trainers/train_base_diffusion.py:164-170 `save` after
+    two Adam steps of the imported reference; oracle/make_golden_ckpt.py) -> trainer.load (train_CXR14.py:105-114) -> cuda ->
+    eps against the eps THE REFERENCE computed from the same file, and the same file through
+    DatasetDM(args.saved_diffusion_model = ...) (models/datasetDM_model.py:38-43) against the reference's extract_features."""
+    from tedm_amd import DatasetDM, trainer
+    path = golden_dir / 'reference_checkpoint_d32.pt'
+    g = np.load(golden_dir / 'reference_checkpoint_d32_probe.npz')
+    dm, _, step = trainer.load(Namespace(device='cpu', lr=1e-4), path)
+    assert step == 2
+    dm.model.precision = prec
+    dm = dm.to(dev).eval()
+    with torch.no_grad():
+        eps = dm.model(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev))
+        x_t = dm._q_sample(torch.from_numpy(g['x0']).to(dev), torch.from_numpy(g['t']).to(dev), torch.from_numpy(g['noise']).to(dev), normalize=True)
+    e, eq = rel(eps, g['eps']), rel(x_t, g['x_t'])
+    print(f'reference checkpoint (dim 32) on the GPU, {prec}: eps vs reference {e:.2e}, q-sample {eq:.1e}')
+    assert eq < 1e-6 and e < (1e-4 if prec == 'bf16x3' else 1e-3)
+    ddm = DatasetDM(Namespace(saved_diffusion_model=str(path), verbose=False, device='cpu', t_steps_to_save=[int(s) for s in g['steps']]))
+    ddm.diffusion_model.model.precision = prec
+    ddm = ddm.to(dev).eval()
+    f = ddm.extract_features(torch.from_numpy(g['x0']).to(dev), noise=torch.from_numpy(g['noise']).to(dev))
+    assert list(f.shape) == [int(v) for v in g['feats_shape']]
+    e1, e2 = rel(f[:, ::3, ::2, ::2], g['feats_sub']), rel(f.mean(dim=(2, 3)), g['feats_mean'])
+    print(f'  DatasetDM(saved_diffusion_model) features vs reference {e1:.2e} (means {e2:.2e})')
+    assert max(e1, e2) < (2e-4 if prec == 'bf16x3' else 2e-3)

@@ -193,3 +193,16 @@ def test_classifier_tail_kernel_dispatch_rules():
     assert not train_tail_supported(tail()[:-1] + [nn.Conv2d(32, 2, 1)], 128)
     assert not train_tail_supported(tail() + [nn.Sigmoid()], 128)
     assert not train_tail_supported(tail(), 256)                      # first-layer width does not match the BatchNorm
+
+
+def test_reference_written_checkpoint_d32_loads(golden_dir):
+    """The reference-written checkpoint the HIP kernels accept (oracle/make_golden_ckpt.py: dim = 32, dim_mults = (1, 2)) on the
+    CPU: loader, module tree (every key, no missing / unexpected), and the oracle reproducing the eps the reference computed."""
+    from tedm_amd import trainer
+    probe = np.load(golden_dir / 'reference_checkpoint_d32_probe.npz')
+    dm, opt, step = trainer.load(Namespace(device='cpu', lr=1e-4), golden_dir / 'reference_checkpoint_d32.pt')
+    assert step == 2 and sum(p.numel() for p in dm.parameters()) == int(probe['n_params'])
+    assert abs(sum(float(p.double().sum()) for p in dm.parameters()) - float(probe['param_sum'])) < 1e-9
+    w = {k: v.detach() for k, v in dm.model.state_dict().items()}
+    eps = O.unet_forward(w, torch.from_numpy(probe['x_t']), torch.from_numpy(probe['t']), dim=32, dim_mults=(1, 2))
+    assert rel(eps, probe['eps']) < 1e-6
