@@ -16,6 +16,10 @@ bool conv_slide_supported(const ConvArgs& a, int KH, int stride, int ups, int pr
 int conv_slide_launch(const ConvArgs& a, int pro, hipStream_t st);
 void conv_slide_label(const ConvArgs& a, int pro, char* buf, int cap);
 extern int g_conv_slide, g_conv_slide_rows;
+// conv_slide128.hip: the same for the 128 -> 64 convs over the decoder's channel concat
+bool conv_slide128_supported(const ConvArgs& a, int KH, int stride, int ups, int pro);
+int conv_slide128_launch(const ConvArgs& a, hipStream_t st);
+void conv_slide128_label(const ConvArgs& a, char* buf, int cap);
 
 int g_conv_prio_mode = 0;      // tedm_set_tuning("conv_prio", 0|1|2)
 int g_conv_solo = 0;           // tedm_set_tuning("conv_solo", 1): pad the LDS request so that workgroups do not share a CU (diagnostic)
@@ -108,6 +112,7 @@ int conv_set_tuning(const char* key, int v) {
 // Label == the rocprof kernel symbol (template argument list of conv_igemm_kernel).
 void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, char* buf, int cap) {
     if (conv_slide_supported(a, KH, stride, ups, pro)) { conv_slide_label(a, pro, buf, cap); return; }
+    if (conv_slide128_supported(a, KH, stride, ups, pro)) { conv_slide128_label(a, buf, cap); return; }
     const int id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(id, stride);
     const int pad = KH == 1 ? 0 : (ups == 3 ? -1 : (ups == 2 ? 2 : 1)), ks = (KH == 1 || a.prec == TEDM_PREC_F16F4 || a.prec == TEDM_PREC_FP16) ? 2 : 1, nbuf = KH == 1 ? 1 : 2;
@@ -138,6 +143,7 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     if (Cin % 16 || a.C1 % 16 || (a.x2 && a.C2 % 16)) return TEDM_EINVAL;
     if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
     if (conv_slide_supported(a, KH, stride, ups, pro)) return conv_slide_launch(a, pro, st);
+    if (conv_slide128_supported(a, KH, stride, ups, pro)) return conv_slide128_launch(a, st);
     const int tile_id = effective_tile(a, KH, stride, ups, pro);
     const TileSel t = tile_geom(tile_id, stride);
     const int TR = t.wm * t.mt;
