@@ -120,6 +120,12 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
     def step():
         return tr.step(x0, t=t, noise=noise)
     elapsed, loss = dp.timed_steps(step, args.steps, args.warmup, dist, dev)
+    # one more step OUTSIDE the timed region with event pairs around every bucket: when the backward had produced it, when its
+    # all-reduce had finished, when the backward had finished, all-reduce GB/s (the overlap evidence of an N > 1 run)
+    tr.timing = True
+    tr._reducer = None
+    tr.step(x0, t=t, noise=noise)
+    comm = tr.comm_report()
     if rank == 0:
         print(json.dumps({
             'metric': 'train-step images/sec @256x256 (fwd + bwd + grad all-reduce + Adam)',
@@ -129,7 +135,8 @@ def bench_train(args, dm, dp, dist, dev, world, rank, x0, t, noise):
             'config': {'workload': f'DiffusionModel.train_step + backward + Adam, {B}x1x{S}x{S} per GPU, global batch {B * world} '
                                    f'(BASELINE configs[3])', 'final_loss': round(float(loss), 6), 'grad_allreduce_buckets': args.buckets if dist is not None else 0,
                        'gradient_parity_vs_fp32_autograd': {'f16f4': '<= 3e-3 per tensor, 5e-4 over all parameters', 'bf16x3': '<= 1e-4 per tensor, 3e-5 overall'}.get(args.prec, 'n/a'),
-                       'train_workspace_GiB': round(dm.model._train_ws.numel() / 2 ** 30, 2)}}), flush=True)
+                       'train_workspace_GiB': round(dm.model._train_ws.numel() / 2 ** 30, 2)},
+            'dist_backend': comm.get('dist_backend'), 'world_size': comm.get('world_size'), 'grad_allreduce': comm}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -378,6 +385,9 @@ def main() -> None:
         'unit': 'img/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.prec,
         'data': 'synthetic',
+        # what torch.distributed itself reports (N > 1: "nccl" IS RCCL on ROCm); the denoise path has no data-path collective,
+        # only the barrier and the max-over-ranks of the elapsed time go through it
+        'dist_backend': dist.get_backend() if dist is not None else None, 'world_size': dist.get_world_size() if dist is not None else 1,
         'config': {'workload': f'TEDM Unet(dim=64,dim_mults=(1,2,4,8),channels=1) q-sample + eps forward, '
                                f'{B}x1x{S}x{S} per GPU (BASELINE configs[1])',
                    'images_per_gpu': B, 'image_size': S, 'params': 36245377,

@@ -63,6 +63,9 @@ typedef struct tedm_unet_cfg {
     int groups;                    /* resnet_block_groups (8) */
     int heads;                     /* attention heads (4)   -- unet_model.py:180,217 */
     int dim_head;                  /* attention head width (32) */
+    int learned_sinusoidal_dim;    /* 0: SinusoidalPosEmb(dim) (unet_model.py:76-93).  > 0 (even): learned_sinusoidal_cond=True with this
+                                      learned_sinusoidal_dim (:96-114,278-285): the parameter `time_mlp.0.weights` (dim/2) replaces the fixed
+                                      frequency table and time_mlp.1 takes learned_sinusoidal_dim + 1 inputs */
 } tedm_unet_cfg;
 
 /* Unet.__init__ (models/unet_model.py:247-331): builds the layer plan (host only; the
@@ -153,6 +156,9 @@ int tedm_unet_backward(tedm_unet* h, const float* d_eps, void* workspace, size_t
  * the generation of the tape now held); tedm_unet_backward_gen fails with TEDM_ESTATE ("tape overwritten by a later
  * forward") when `generation` is not the tape's -- use it whenever two forwards can be outstanding (autograd). */
 long long tedm_unet_tape_generation(const tedm_unet* h);
+/* Where the training forward left the output of ups[level][2] (the tensor models/datasetDM_model.py:50-53 hooks), inside the
+ * training workspace: byte offset and NHWC shape (B, H, W, C).  Valid until the tape is consumed or overwritten. */
+int tedm_unet_tape_tap(const tedm_unet* h, int level, size_t* offset_bytes, int shape[4]);
 int tedm_unet_backward_gen(tedm_unet* h, const float* d_eps, void* workspace, size_t workspace_bytes, void* stream,
                            long long generation);
 /* Data-parallel training (not in the reference, which has no distributed code): `fn(user, group)` is called from
@@ -212,9 +218,11 @@ int tedm_head_tail_nhwc(const float* const* z, const int* h, const int* w, int n
  * passes).  `blocks` = number of per-block partial results the caller allocated = workgroups launched; partials are summed by the
  * caller in a fixed order (deterministic).  a / b: BatchNorm as y = a x + b; k [3][32], m [3][C1]: coefficients of
  * dz2 = [z2 > 0] (k0 dl + k1 + k2 z2) and dh1 = [h1 > 0] (m0 du + m1 + m2 h1), du = W2^T dz2. */
-int tedm_head_train_stats1(const float* h1, long long P, int C1, float* part /*[blocks][C1][2]*/, int blocks, void* stream);
+ /* shift / shift2 (per channel, may be NULL = 0): the (sum, sumsq) partials are taken of (x - shift) -- a shift near the channel mean
+ * keeps the batch variance exact in fp32 for channels with |mean| >> std. */
+int tedm_head_train_stats1(const float* h1, long long P, int C1, const float* shift /*[C1]*/, float* part /*[blocks][C1][2]*/, int blocks, void* stream);
 int tedm_head_train_mid(const float* h1, long long P, int C1, const float* a1, const float* b1, const float* w2t /*[C1][32]*/,
-                        const float* bias2, float* z2 /*[P][32]*/, float* part2 /*[blocks][32][2]*/, int blocks, void* stream);
+                        const float* bias2, const float* shift2 /*[32]*/, float* z2 /*[P][32]*/, float* part2 /*[blocks][32][2]*/, int blocks, void* stream);
 int tedm_head_train_out(const float* z2, long long P, const float* a2, const float* b2, const float* w3, const float* b3,
                         float* logits /*[P]*/, void* stream);
 int tedm_head_train_bwd1(const float* z2, const float* dl, long long P, float* part /*[blocks][33]: A1[32], A0*/, int blocks, void* stream);

@@ -10,7 +10,8 @@ the imported reference `DiffusionModel` after two Adam steps (trainers/train_CXR
 To keep the fixture at 3.3 MB the Adam moments are NOT stored: `save` is handed a fresh optimizer over the trained parameters
 (the populated optimizer state of a reference checkpoint is what the d8 fixture covers).
 
-    python oracle/make_golden_ckpt.py
+    python oracle/make_golden_ckpt.py            # the checkpoint fixtures
+    python oracle/make_golden_ckpt.py --learned  # learned_sinusoidal_cond golden (models/unet_model.py:96-114)
 """
 import sys
 from argparse import Namespace
@@ -72,5 +73,37 @@ def main():
         raise SystemExit('oracle restatement deviates from the reference by more than 1e-5')
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--learned' not in sys.argv:
     main()
+
+
+def learned_sinusoid_golden():
+    """`learned_sinusoidal_cond=True` (models/unet_model.py:96-114,278-285) -- the reference Unet with the
+    build's synthetic weights (incl. the learned frequency vector), eps on a 32x32 probe and the gradient of the sum-of-eps * R
+    probe w.r.t. `time_mlp.0.weights`; the oracle restatement must agree."""
+    from oracle import unet_ref as O
+    from tedm_amd.weights import synth_state_dict
+    RUnet, _, _ = import_reference()
+    torch.manual_seed(0)
+    ref = RUnet(32, dim_mults=(1, 2), channels=1, learned_sinusoidal_cond=True, learned_sinusoidal_dim=16)
+    keys = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    w = synth_state_dict(keys, seed=3)
+    ref.load_state_dict(w)
+    x0, t, R = inputs(2, 32, 77)
+    x = x0 * 2 - 1
+    with torch.enable_grad():
+        eps = ref(x, t)
+        (eps * R).sum().backward()
+    gw = ref.time_mlp[0].weights.grad.clone()
+    g1 = ref.time_mlp[1].weight.grad.clone()
+    with torch.no_grad():
+        e = rel(O.unet_forward({k: v.detach() for k, v in ref.state_dict().items()}, x, t, dim=32, dim_mults=(1, 2)), eps.detach())
+    np.savez(GOLD / 'learned_sinusoid_d32_s32.npz', x=x.numpy(), t=t.numpy(), R=R.numpy(), eps=eps.detach().numpy(),
+             grad_weights=gw.numpy(), grad_mlp1=g1.numpy(), keys=np.array(sorted(keys)), fourier_in=np.int64(ref.time_mlp[1].in_features))
+    print(f'learned sinusoid: {len(keys)} keys, time_mlp.1 in_features {ref.time_mlp[1].in_features}, eps oracle vs reference rel-L2 {e:.3e}')
+    if e > 1e-5:
+        raise SystemExit('oracle restatement deviates from the reference by more than 1e-5')
+
+
+if __name__ == '__main__' and '--learned' in sys.argv:
+    learned_sinusoid_golden()

@@ -85,9 +85,16 @@ def sinusoidal_emb(t: Tensor, dim: int) -> Tensor:
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
+def learned_sinusoidal_emb(t: Tensor, weights: Tensor) -> Tensor:
+    """models/unet_model.py:96-114 (LearnedSinusoidalPosEmb.forward): cat(t, sin(f), cos(f)), f = t * weights * 2 * pi."""
+    t = t[:, None]
+    freqs = t * weights[None, :] * 2 * math.pi
+    return torch.cat((t, freqs.sin(), freqs.cos()), dim=-1)
+
+
 def time_mlp(p: Params, t: Tensor, dim: int) -> Tensor:
-    """models/unet_model.py:287-292 -- sinusoid -> Linear -> exact-erf GELU -> Linear."""
-    e = sinusoidal_emb(t, dim)
+    """models/unet_model.py:278-292 -- (learned) sinusoid -> Linear -> exact-erf GELU -> Linear."""
+    e = learned_sinusoidal_emb(t, p['time_mlp.0.weights']) if 'time_mlp.0.weights' in p else sinusoidal_emb(t, dim)
     e = F.linear(e, p['time_mlp.1.weight'], p['time_mlp.1.bias'])
     e = F.gelu(e)
     return F.linear(e, p['time_mlp.3.weight'], p['time_mlp.3.bias'])

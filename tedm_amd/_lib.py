@@ -21,7 +21,7 @@ PREC_BY_NAME = {'bf16x3': PREC_BF16X3, 'bf16': PREC_BF16, 'fp16x2': PREC_FP16X2,
 class UnetCfg(C.Structure):
     _fields_ = [('dim', C.c_int), ('init_dim', C.c_int), ('out_dim', C.c_int), ('n_mults', C.c_int),
                 ('dim_mults', C.c_int * TEDM_MAX_LEVELS), ('channels', C.c_int), ('groups', C.c_int),
-                ('heads', C.c_int), ('dim_head', C.c_int)]
+                ('heads', C.c_int), ('dim_head', C.c_int), ('learned_sinusoidal_dim', C.c_int)]
 
 
 BACKWARD_MARK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)      # tedm_hip.h: tedm_backward_mark_fn
@@ -52,6 +52,7 @@ _SIGNATURES = {
     'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     'tedm_unet_backward_gen': (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_longlong]),
     'tedm_unet_tape_generation': (C.c_longlong, [_P]),
+    'tedm_unet_tape_tap': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     'tedm_unet_set_backward_callback': (C.c_int, [_P, _P, _P]),
     'tedm_l1_loss': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, _P, _P, _P, _P]),
     'tedm_unet_module_channels': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -65,8 +66,8 @@ _SIGNATURES = {
     'tedm_upsample_sum_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'tedm_pool_sum_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'tedm_head_tail_nhwc': (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
-    'tedm_head_train_stats1': (C.c_int, [_P, C.c_longlong, C.c_int, _P, C.c_int, _P]),
-    'tedm_head_train_mid': (C.c_int, [_P, C.c_longlong, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    'tedm_head_train_stats1': (C.c_int, [_P, C.c_longlong, C.c_int, _P, _P, C.c_int, _P]),
+    'tedm_head_train_mid': (C.c_int, [_P, C.c_longlong, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     'tedm_head_train_out': (C.c_int, [_P, C.c_longlong, _P, _P, _P, _P, _P, _P]),
     'tedm_head_train_bwd1': (C.c_int, [_P, _P, C.c_longlong, _P, C.c_int, _P]),
     'tedm_head_train_bwd2': (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_int, _P]),

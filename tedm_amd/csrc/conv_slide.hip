@@ -30,6 +30,21 @@ constexpr int SL_ROWB = SL_NC * SL_SEG;      // bytes of a ring row
 constexpr int SL_ZERO = SL_NR * SL_ROWB;     // byte offset of the all-zero row
 constexpr int SL_LDS = SL_ZERO + SL_ROWB;    // 148 960 B
 
+// silu(a x + b) of two channels with the packed-fp32 forms (v_pk_fma / v_pk_mul / v_pk_add: one instruction per pair) around the
+// two transcendentals per channel: the same five operations per channel as silu_f (common.h) behind the same fma, hence the same
+// bits -- every instruction between two MFMAs of this single-wave kernel costs ~3 cycles whatever it is.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+TEDM_DEVFN void silu2_gn(float& x0, float& x1, float a0, float a1, float b0, float b1) {
+#pragma clang fp contract(off)
+    const f32x2 v = __builtin_elementwise_fma((f32x2){a0, a1}, (f32x2){x0, x1}, (f32x2){b0, b1});
+    const f32x2 t = v * (f32x2){-1.44269504088896340736f, -1.44269504088896340736f};       // 0xbfb8aa3b
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = e + (f32x2){1.f, 1.f};
+    const f32x2 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 y = v * rc;
+    x0 = y[0]; x1 = y[1];
+}
+
 template <int PRO, bool ST>
 __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int rows_wg) {
     constexpr int NC = SL_NC;
@@ -171,8 +186,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
             constexpr int n = sl_vm_after(k, PRO == PRO_GN ? 0 : 8, ST, ABL);
             __builtin_amdgcn_s_waitcnt(sl_vmcnt_imm(n > 63 ? 63 : n));
         }
-        if constexpr (sp < 8) {                                  // prologue: silu(a x + b), one channel per stage
-            if constexpr (PRO == PRO_GN) x[sp] = silu_f(fmaf(pa[sp], x[sp], pb[sp]));
+        if constexpr (sp < 8) {                                  // prologue: silu(a x + b), two channels per even stage
+            if constexpr (PRO == PRO_GN && (sp & 1) == 0) silu2_gn(x[sp], x[sp + 1], pa[sp], pa[sp + 1], pb[sp], pb[sp + 1]);
         } else if constexpr (sp == 8 || sp == 9) {               // block maximum: |.| of four channels per stage
             constexpr int e = (sp - 8) * 4;
             float m = sp == 8 ? 0.f : __builtin_bit_cast(float, em);
@@ -239,6 +254,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
     const unsigned lane_off = (unsigned)(4 * h * 64 + cout);
     const int E = (H >> 2) * a.tiles_x;
     float s1 = 0.f, s2 = 0.f;
+#ifdef SL_FILL
+    float fill[8] = {0.f, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f};
+#endif
 
     // The band body is ONE straight-line block, written in the order it should issue: a wave alone on its SIMD overlaps nothing
     // by itself -- whatever VALU / LDS / VMEM work stands BETWEEN two MFMAs in program order runs in the first one's shadow
@@ -360,6 +378,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
                         if constexpr (u % 3 == 1 && u / 3 < 32 && !(ABL & 4))
                             epi_value(std::integral_constant<int, ph ^ 1>{}, std::integral_constant<int, u / 3>{});
                         if constexpr (ph == 0 && u == 97) epi_stats(oyp);
+#ifdef SL_FILL      // tools/slide_lab.hip: SL_FILL independent VALU instructions behind every MFMA (what does an MFMA's shadow hide?)
+#pragma unroll
+                        for (int f = 0; f < SL_FILL; ++f) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fill[f % 8]) : "v"(bias));
+#endif
                         SL_SCHED();
                     });
                 }
@@ -371,6 +393,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
         __syncthreads();
         SL_STAMP(3);
     }
+#ifdef SL_FILL
+    if (a.trace && blockIdx.x == 0xffffff) for (int j = 0; j < 8; ++j) a.out[j] = fill[j];
+#endif
     // rows 2, 3 of the last band
     {
         const int oy = y0 + 8 * (nb - 1) + 4 * rh + 2;

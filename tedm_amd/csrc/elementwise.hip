@@ -311,18 +311,29 @@ __global__ __launch_bounds__(256) void stem_conv_f16_kernel(const float* __restr
 __global__ __launch_bounds__(256) void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                   int dim, int tdim, float* __restrict__ st /*[B][tdim]*/,
+                                                   int dim, int tdim, int learned, float* __restrict__ st /*[B][tdim]*/,
                                                    float* __restrict__ save /*training tape or NULL*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* emb = (float*)smem;         // [dim]
     float* hid = emb + dim;            // [tdim]
-    const int b = blockIdx.x, half = dim / 2, B = gridDim.x;
+    const int b = blockIdx.x, half = learned ? (dim - 1) / 2 : dim / 2, B = gridDim.x;
     // tape sections: emb [B][dim] | pre-GELU [B][tdim] | post-GELU [B][tdim] | pre-SiLU [B][tdim]
     float* s_emb = save ? save + (size_t)b * dim : nullptr;
     float* s_t1 = save ? save + (size_t)B * dim + (size_t)b * tdim : nullptr;
     float* s_hg = save ? s_t1 + (size_t)B * tdim : nullptr;
     float* s_t2 = save ? s_hg + (size_t)B * tdim : nullptr;
     const float tv = t[b];
+    if (learned) {
+        // LearnedSinusoidalPosEmb (models/unet_model.py:96-114): cat(t, sin(f), cos(f)), f = t * weights * 2 * pi evaluated left
+        // to right in fp32 as torch does (python scalars multiply as fp32)
+        if (threadIdx.x == 0) { emb[0] = tv; if (save) s_emb[0] = tv; }
+        for (int i = threadIdx.x; i < half; i += blockDim.x) {
+            const float a = __fmul_rn(__fmul_rn(__fmul_rn(tv, freqs[i]), 2.f), 3.14159265358979323846f);
+            emb[1 + i] = sinf(a);
+            emb[1 + half + i] = cosf(a);
+            if (save) { s_emb[1 + i] = emb[1 + i]; s_emb[1 + half + i] = emb[1 + half + i]; }
+        }
+    } else
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         const float a = tv * freqs[i];
         emb[i] = sinf(a);
@@ -689,6 +700,8 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 // Both 1x1 convolutions are linear, so the 64-channel block output never has to exist: one pass reads x1, x2, y2 and writes OD
 // values per pixel, in fp32 (no MFMA: 192 FMAs + 64 SiLU per pixel against 768 bytes of HBM reads).
 // fold: wfold[o][0..C1+C2) = Wf[o] W_res, wfold[o][C1+C2] = Wf[o] . b_res + bf[o]        (one block)
+// Row stride Cin + 4 floats (a multiple of 4: the fused kernel reads the rows with 16-byte loads; an odd stride of Cin + 1 left
+// every row o >= 1 only 4-byte aligned -- ADVICE r3)
 __global__ __launch_bounds__(256) void final_fold_kernel(const float* __restrict__ wf, const float* __restrict__ bf,
                                                          const float* __restrict__ wres, const float* __restrict__ bres,
                                                          int OD, int C, int Cin, float* __restrict__ wfold) {
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(256) void final_fold_kernel(const float* __restrict
         float s = 0.f;
         if (j < Cin) { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], wres[(size_t)c * Cin + j], s); }
         else { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], bres ? bres[c] : 0.f, s); s += bf ? bf[o] : 0.f; }
-        wfold[i] = s;
+        wfold[(size_t)o * (Cin + 4) + j] = s;
     }
 }
 
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(256) void final_fused_kernel(const float* __restric
                 sv[v].z = silu_f(fmaf(aa[u][v].z, yy[u][v].z, bb[u][v].z)); sv[v].w = silu_f(fmaf(aa[u][v].w, yy[u][v].w, bb[u][v].w));
             }
             for (int o = 0; o < OD; ++o) {
-                const float* wo = wfold + (size_t)o * (2 * C + 1);
+                const float* wo = wfold + (size_t)o * (2 * C + 4);
                 float s = 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
@@ -924,9 +937,28 @@ int op_stem_conv(const float* x, const float* w, const float* bias, float* out, 
 }
 
 int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
-                  const float* b2, int B, int dim, int tdim, float* st_out, float* save, hipStream_t st) {
+                  const float* b2, int B, int dim, int tdim, int learned, float* st_out, float* save, hipStream_t st) {
     hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(256), (size_t)(dim + tdim) * 4, st, t, freqs, w1, b1, w2, b2, dim,
-                       tdim, st_out, save);
+                       tdim, learned, st_out, save);
+    return LAUNCH_OK();
+}
+
+// f = 2 pi t w  =>  d w[i] = sum_b (d sin_i cos_i - d cos_i sin_i) * 2 pi t_b   (sin, cos, t read back from the saved embedding)
+__global__ __launch_bounds__(64) void learned_sinusoid_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ emb, int B,
+                                                                  int half, float* __restrict__ dw) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= half) return;
+    const int D = 2 * half + 1;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* e = emb + (size_t)b * D;
+        const float* d = demb + (size_t)b * D;
+        s = fmaf(fmaf(d[1 + i], e[1 + half + i], -d[1 + half + i] * e[1 + i]), 6.28318530717958647692f * e[0], s);
+    }
+    dw[i] = s;
+}
+int op_learned_sinusoid_backward(const float* demb, const float* emb, int B, int half, float* dw, hipStream_t st) {
+    hipLaunchKernelGGL(learned_sinusoid_bwd_kernel, dim3((half + 63) / 64), dim3(64), 0, st, demb, emb, B, half, dw);
     return LAUNCH_OK();
 }
 
@@ -1009,7 +1041,7 @@ int op_final_conv(const float* x, const float* w, const float* bias, float* out,
     return LAUNCH_OK();
 }
 
-// wfold: OD * (2C + 1) floats of scratch (written here, read by the fused kernel on the same stream)
+// wfold: OD * (2C + 4) floats of scratch (written here, read by the fused kernel on the same stream)
 int op_final_fused(const float* x1, const float* x2, const float* y2, const float* ga, const float* gb, const float* wres,
                    const float* bres, const float* wf, const float* bf, float* wfold, float* out_nchw, int B, long long hw,
                    int C, int OD, hipStream_t st) {

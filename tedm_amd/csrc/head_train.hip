@@ -26,14 +26,18 @@ namespace {
 constexpr int HP = 256, HL = 33;             // pixels per tile of the pixel-owner kernels, padded LDS row
 
 // ---- forward 1: per-channel (sum, sumsq) of relu(h1) ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ht_stats1_kernel(const float* __restrict__ h1, long long P, int C1, float* __restrict__ part) {
+// Sums are taken of (x - shift[c]) (shift = the BatchNorm's running mean; null = 0): E[x^2] - mean^2 from fp32 sums loses the
+// variance of a channel whose mean is large against its spread; around a shift near the mean it does not.
+__global__ __launch_bounds__(256) void ht_stats1_kernel(const float* __restrict__ h1, long long P, int C1, const float* __restrict__ shift,
+                                                        float* __restrict__ part) {
     __shared__ float4 red[2][256];
     const int C4 = C1 >> 2, ppb = 256 / C4;
     const int tid = threadIdx.x, c4 = tid % C4, g = tid / C4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    const float4 sh = shift ? *(const float4*)(shift + c4 * 4) : s;
     for (long long p = (long long)blockIdx.x * ppb + g; p < P; p += (long long)gridDim.x * ppb) {
         const float4 v = *(const float4*)(h1 + (size_t)p * C1 + c4 * 4);
-        const float a = fmaxf(v.x, 0.f), b = fmaxf(v.y, 0.f), c = fmaxf(v.z, 0.f), d = fmaxf(v.w, 0.f);
+        const float a = fmaxf(v.x, 0.f) - sh.x, b = fmaxf(v.y, 0.f) - sh.y, c = fmaxf(v.z, 0.f) - sh.z, d = fmaxf(v.w, 0.f) - sh.w;
         s.x += a; s.y += b; s.z += c; s.w += d;
         q.x = fmaf(a, a, q.x); q.y = fmaf(b, b, q.y); q.z = fmaf(c, c, q.z); q.w = fmaf(d, d, q.w);
     }
@@ -53,7 +57,8 @@ __global__ __launch_bounds__(256) void ht_stats1_kernel(const float* __restrict_
 // ---- forward 2: z2 = W2 (a1 relu(h1) + b1) + bias2 and the statistics of relu(z2) -----------------------------------------
 __global__ __launch_bounds__(256) void ht_mid_kernel(const float* __restrict__ h1, long long P, int C1, const float* __restrict__ a1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2t /*[C1][32]*/,
-                                                     const float* __restrict__ bias2, float* __restrict__ z2, float* __restrict__ part2) {
+                                                     const float* __restrict__ bias2, const float* __restrict__ shift2 /*[32] or null*/,
+                                                     float* __restrict__ z2, float* __restrict__ part2) {
     __shared__ float sa[HP * HL];
     __shared__ float red[2][256];
     const int tid = threadIdx.x;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void ht_mid_kernel(const float* __restrict__ h
         }
         float* row = sa + tid * HL;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) row[j] = ok ? fmaxf(acc[j], 0.f) : 0.f;
+        for (int j = 0; j < 32; ++j) row[j] = ok ? fmaxf(acc[j], 0.f) - (shift2 ? shift2[j] : 0.f) : 0.f;
         __syncthreads();
         {
             const int c = tid & 31, g = tid >> 5;
@@ -332,15 +337,15 @@ extern "C" {
 
 // Every function: device pointers, P = pixels (B*S*S), `blocks` = number of per-block partials the caller allocated (>= 1; the
 // launch uses exactly that many workgroups).  C1: a power of two in [32, 1024] (stats1), a multiple of 32 (mid, bwd3), 128 or 256 (bwd2).
-int tedm_head_train_stats1(const float* h1, long long P, int C1, float* part, int blocks, void* stream) {
+int tedm_head_train_stats1(const float* h1, long long P, int C1, const float* shift, float* part, int blocks, void* stream) {
     if (!h1 || !part || P < 1 || blocks < 1 || C1 < 32 || C1 > 1024 || (C1 & (C1 - 1))) return TEDM_EINVAL;
-    hipLaunchKernelGGL(ht_stats1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h1, P, C1, part);
+    hipLaunchKernelGGL(ht_stats1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h1, P, C1, shift, part);
     return LAUNCH_OK();
 }
 int tedm_head_train_mid(const float* h1, long long P, int C1, const float* a1, const float* b1, const float* w2t, const float* bias2,
-                        float* z2, float* part2, int blocks, void* stream) {
+                        const float* shift2, float* z2, float* part2, int blocks, void* stream) {
     if (!h1 || !a1 || !b1 || !w2t || !bias2 || !z2 || !part2 || P < 1 || blocks < 1 || C1 % 32 || C1 < 32) return TEDM_EINVAL;
-    hipLaunchKernelGGL(ht_mid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h1, P, C1, a1, b1, w2t, bias2, z2, part2);
+    hipLaunchKernelGGL(ht_mid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h1, P, C1, a1, b1, w2t, bias2, shift2, z2, part2);
     return LAUNCH_OK();
 }
 int tedm_head_train_out(const float* z2, long long P, const float* a2, const float* b2, const float* w3, const float* b3, float* logits,
@@ -360,11 +365,8 @@ int tedm_head_train_bwd2(const float* h1, const float* z2, const float* dl, long
     const size_t lds = (size_t)(64 * (C1 + 4) + 64 * 36) * sizeof(float);
     if (C1 == 128) hipLaunchKernelGGL(ht_bwd2_kernel<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, h1, z2, dl, P, k, part);
     else {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)ht_bwd2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEDM_EHIP;
-            attr = true;
-        }
+        // (the attribute is per DEVICE and the call is cheap: no process-wide flag -- ADVICE r3)
+        if (hipFuncSetAttribute((const void*)ht_bwd2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEDM_EHIP;
         hipLaunchKernelGGL(ht_bwd2_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, h1, z2, dl, P, k, part);
     }
     return LAUNCH_OK();

@@ -7,8 +7,11 @@ int op_q_sample(const float* x0, const float* noise, const long long* t, const f
                 float* xt, int B, long long chw, int normalize, hipStream_t st);
 int op_stem_conv(const float* x_nchw, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                  int Cout, hipStream_t st);
+// dim: width of the embedding fed to time_mlp.1; learned != 0: LearnedSinusoidalPosEmb (freqs = its `weights`, (dim - 1) / 2 of them)
 int op_time_embed(const float* t, const float* freqs, const float* w1, const float* b1, const float* w2,
-                  const float* b2, int B, int dim, int tdim, float* st_out, float* save /*tape or NULL*/, hipStream_t st);
+                  const float* b2, int B, int dim, int tdim, int learned, float* st_out, float* save /*tape or NULL*/, hipStream_t st);
+// d weights of LearnedSinusoidalPosEmb from d emb [B][2 half + 1] and the saved embedding [B][2 half + 1] = (t, sin, cos)
+int op_learned_sinusoid_backward(const float* demb, const float* emb, int B, int half, float* dw, hipStream_t st);
 int op_film(const float* st_in, const float* wf, const float* bf, int B, int tdim, int J, float* film, hipStream_t st);
 int op_gn_finalize(const float* slab, int E, int B, int C, int groups, long long hw, const float* gamma,
                    const float* beta, const float* film, int film_stride, float* oa, float* ob, float* mr_out,

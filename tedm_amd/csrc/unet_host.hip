@@ -201,6 +201,8 @@ int g_la_fused = 2;   // tedm_set_tuning("la_fused", v): 0 qkv-tensor path, 1 th
 struct tedm_unet {
     tedm_unet_cfg cfg;
     int init_dim = 0, out_dim = 0, tdim = 0, nres = 0, hidden = 0;
+    int fdim = 0;                  // width of the time embedding fed to time_mlp.1: dim, or learned_sinusoidal_dim + 1
+    const float* temb_table() const { return P(cfg.learned_sinusoidal_dim ? "time_mlp.0.weights" : "time_mlp.0.freqs"); }
     std::vector<int> dims;
     std::vector<Param> params;
     std::map<std::string, int> index;
@@ -299,8 +301,12 @@ int build_plan(tedm_unet* u) {
     // state-dict order of models/unet_model.py:267-331
     u->add_param("init_conv.weight", (long long)u->init_dim * c.channels * 49);
     u->add_param("init_conv.bias", u->init_dim);
-    u->add_param("time_mlp.0.freqs", c.dim / 2);   // facade-bound table (not a reference key)
-    u->add_param("time_mlp.1.weight", (long long)u->tdim * c.dim);
+    // time embedding: fixed sinusoid table (facade-bound, not a reference key) or the learned frequencies (unet_model.py:96-114)
+    if (c.learned_sinusoidal_dim < 0 || c.learned_sinusoidal_dim % 2 || c.learned_sinusoidal_dim > 1024) return fail(TEDM_EINVAL, "bad learned_sinusoidal_dim %d", c.learned_sinusoidal_dim);
+    u->fdim = c.learned_sinusoidal_dim ? c.learned_sinusoidal_dim + 1 : c.dim;
+    if (c.learned_sinusoidal_dim) u->add_param("time_mlp.0.weights", c.learned_sinusoidal_dim / 2);
+    else u->add_param("time_mlp.0.freqs", c.dim / 2);
+    u->add_param("time_mlp.1.weight", (long long)u->tdim * u->fdim);
     u->add_param("time_mlp.1.bias", u->tdim);
     u->add_param("time_mlp.3.weight", (long long)u->tdim * u->tdim);
     u->add_param("time_mlp.3.bias", u->tdim);
@@ -432,7 +438,7 @@ struct Fwd {
            op_gn_finalize(slab, E, B, C, u->cfg.groups, hw, u->P(r.pre + ".block2.norm.weight"),
                           u->P(r.pre + ".block2.norm.bias"), nullptr, 0, ga, gb, nullptr, st));
         if (fuse_final) {
-            float* wfold = A->alloc((size_t)u->out_dim * (2 * C + 1));
+            float* wfold = A->alloc((size_t)u->out_dim * (2 * C + 4));
             OP("final_fused", 2.0 * B * hw * u->out_dim * 3 * C, 4.0 * B * hw * (3 * C + u->out_dim),
                op_final_fused(x1, x2, y2, ga, gb, u->P(r.res.key + ".weight"), r.res.has_bias ? u->P(r.res.key + ".bias") : nullptr,
                               u->P("final_conv.weight"), u->P("final_conv.bias"), wfold, final_eps, B, hw, C, u->out_dim, st));
@@ -572,9 +578,9 @@ struct Fwd {
         if (film) {
             float* stb = A->alloc((size_t)B * u->tdim);
             filmbuf = A->alloc((size_t)B * u->film_J);
-            OP("time_embed", 2.0 * B * u->tdim * (dim + u->tdim), 4.0 * u->tdim * (dim + u->tdim),
-               op_time_embed(t, u->P("time_mlp.0.freqs"), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
-                             u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, dim, u->tdim, stb, nullptr, st));
+            OP("time_embed", 2.0 * B * u->tdim * (u->fdim + u->tdim), 4.0 * u->tdim * (u->fdim + u->tdim),
+               op_time_embed(t, u->temb_table(), u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"),
+                             u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), B, u->fdim, u->tdim, u->cfg.learned_sinusoidal_dim != 0, stb, nullptr, st));
             OP("film_proj", 2.0 * B * u->tdim * u->film_J, 4.0 * u->tdim * u->film_J,
                op_film(stb, u->film_w, u->film_b, B, u->tdim, u->film_J, filmbuf, st));
             A->release(stb);
@@ -895,6 +901,17 @@ int tedm_unet_forward_train(tedm_unet* h, const float* x, const float* t, int B,
 }
 
 long long tedm_unet_tape_generation(const tedm_unet* h) { return h ? h->tape_gen : 0; }
+
+int tedm_unet_tape_tap(const tedm_unet* h, int level, size_t* offset_bytes, int shape[4]) {
+    g_err[0] = 0;
+    if (!h || !offset_bytes || !shape) return fail(TEDM_EINVAL, "null argument");
+    const Tape& T = h->tape;
+    if (!T.valid) return fail(TEDM_ESTATE, "no training tape (call tedm_unet_forward_train first)");
+    if (level < 0 || level >= h->nres || (size_t)level >= T.ut.size() || !T.ut[level].in) return fail(TEDM_EINVAL, "bad tap level %d", level);
+    *offset_bytes = (size_t)((const char*)T.ut[level].in - T.arena.base);
+    shape[0] = T.B; shape[1] = T.ut[level].H; shape[2] = T.ut[level].W; shape[3] = h->dims[h->nres - level];
+    return TEDM_OK;
+}
 
 int tedm_unet_set_backward_callback(tedm_unet* h, tedm_backward_mark_fn fn, void* user) {
     g_err[0] = 0;

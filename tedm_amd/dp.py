@@ -8,6 +8,7 @@ for tests) only carries the barrier and the max-over-ranks of the elapsed time.
 from __future__ import annotations
 
 import os
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -177,42 +178,120 @@ class BucketedGradReducer:
     and summed over ranks exactly as by the single-buffer `allreduce_grads_` (bit-identical on 2 ranks, tests/test_dp_gloo.py).
     Works on CPU tensors (gloo) for tests: no streams, the collectives run inline."""
 
-    def __init__(self, dist, flat: torch.Tensor, buckets, local_n: int, global_n: int):
+    def __init__(self, dist, flat: torch.Tensor, buckets, local_n: int, global_n: int, timing: bool = False):
         self.dist, self.flat, self.buckets = dist, flat, list(buckets)
-        self.scale = None if local_n == global_n else local_n / float(global_n)
         self.by_group = {g: (lo, hi) for g, lo, hi in self.buckets}
         self.cuda = flat.is_cuda
-        self.side = torch.cuda.Stream(flat.device) if self.cuda else None
-        self.pending, self.done = [], []
+        self.side = torch.cuda.Stream(flat.device) if self.cuda else None        # ONE side stream for the reducer's lifetime
+        self.timing = timing
+        self.pending, self.done, self.marks, self.failed = [], [], [], None
+        self.t0 = None
+        self.reset(local_n, global_n)
+
+    def reset(self, local_n: int, global_n: int) -> None:
+        """Start of a step (before the training forward): the reducer and its stream are reused, only the per-step state resets."""
+        self.scale = None if local_n == global_n else local_n / float(global_n)
+        self.pending, self.done, self.marks, self.failed = [], [], [], None
+        if self.timing:
+            if self.cuda:
+                self.t0 = torch.cuda.Event(enable_timing=True)
+                self.t0.record(torch.cuda.current_stream(self.flat.device))
+            else:
+                self.t0 = time.perf_counter()
 
     def on_group(self, name: str) -> None:
         span = self.by_group.get(name)
-        if span is None or self.dist is None:
+        if span is None or self.dist is None or self.failed is not None:
             return
-        lo, hi = span
+        try:
+            self._reduce(name, *span)
+        except BaseException as e:        # raised inside the C backward's callback: remember it, tell the peers, re-raise in finish()
+            self.failed = e
+            self._abort_peers()
+
+    def _reduce(self, name: str, lo: int, hi: int) -> None:
         sl = self.flat[lo:hi]
         self.done.append(name)
         if not self.cuda:
+            t_closed = time.perf_counter()
             if self.scale is not None:
                 sl.mul_(self.scale)
             self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM)
+            if self.timing:
+                self.marks.append((name, hi - lo, t_closed, time.perf_counter()))
             return
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=self.timing)
         ev.record(torch.cuda.current_stream(self.flat.device))
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             if self.scale is not None:
                 sl.mul_(self.scale)
-            self.pending.append(self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM, async_op=True))
+            work = self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM, async_op=True)
+            self.pending.append(work)
+            if self.timing:
+                work.wait()                                  # (side stream only: the compute stream keeps running the backward)
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(self.side)
+                self.marks.append((name, hi - lo, ev, done))
+
+    def _abort_peers(self) -> None:
+        """A rank that fails between two buckets has issued fewer collectives than its peers, which would wait for it until the
+        backend's timeout.  Tear the process group down so that their pending collective fails now."""
+        try:
+            import torch.distributed as tdist
+            pg = tdist.distributed_c10d._get_default_group()
+            for meth in ('abort', '_abort', '_shutdown'):
+                be = None
+                try:
+                    be = pg._get_backend(self.flat.device)
+                except Exception:
+                    pass
+                if be is not None and hasattr(be, meth):
+                    getattr(be, meth)()
+                    return
+            tdist.destroy_process_group()
+        except Exception:
+            pass
 
     def finish(self) -> None:
+        if self.failed is not None:
+            raise RuntimeError(f'bucketed all-reduce failed after the groups {self.done}; the process group was torn down so '
+                               f'that the other ranks fail instead of waiting') from self.failed
         if len(self.done) != len(self.buckets) and self.dist is not None:
             raise RuntimeError(f'bucketed all-reduce: backward reported {self.done}, expected the groups {[b[0] for b in self.buckets]}')
         for w in self.pending:
             w.wait()                                         # the current stream waits for the collective
         if self.cuda:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self.timing:
+                self.t_bwd = torch.cuda.Event(enable_timing=True)
+                self.t_bwd.record(cur)                       # every backward kernel is enqueued in front of this
+            cur.wait_stream(self.side)
+        elif self.timing:
+            self.t_bwd = time.perf_counter()
         self.pending = []
+
+    def report(self) -> dict:
+        """Per-bucket event times of the last step (timing=True), milliseconds since `reset()`: when the backward had produced
+        the bucket, when its all-reduce had finished, when the whole backward had finished; all-reduce GB/s = payload bytes over
+        (done - max(closed, previous done)).  Synchronises the device."""
+        if not self.timing or self.t0 is None:
+            return {}
+        out, prev_done = [], 0.0
+        if self.cuda:
+            torch.cuda.synchronize(self.flat.device)
+            ms = lambda e: self.t0.elapsed_time(e)
+        else:
+            ms = lambda t: (t - self.t0) * 1e3
+        for name, n, closed, done in self.marks:
+            c, d = ms(closed), ms(done)
+            busy = max(d - max(c, prev_done), 1e-6)
+            out.append({'last_group': name, 'elements': int(n), 'closed_ms': round(c, 3), 'allreduce_done_ms': round(d, 3),
+                        'allreduce_gb_per_s': round(4.0 * n / busy / 1e6, 2)})
+            prev_done = d
+        bwd = ms(self.t_bwd) if getattr(self, 't_bwd', None) is not None else None
+        return {'buckets': out, 'backward_done_ms': None if bwd is None else round(bwd, 3),
+                'hidden_under_backward': bool(out) and bwd is not None and all(b['allreduce_done_ms'] <= bwd for b in out[:-1])}
 
 
 class DataParallelTrainer:
@@ -222,9 +301,10 @@ class DataParallelTrainer:
     forward+backward on its shard, all-reduces `dm.model.grad_flat` once and applies the same optimizer
     update (so replicas stay bit-identical when the collective is deterministic)."""
 
-    def __init__(self, dm, optimizer, dist=None, n_buckets: int = 4):
-        self.dm, self.opt, self.dist, self.n_buckets = dm, optimizer, dist, n_buckets
+    def __init__(self, dm, optimizer, dist=None, n_buckets: int = 4, timing: bool = False):
+        self.dm, self.opt, self.dist, self.n_buckets, self.timing = dm, optimizer, dist, n_buckets, timing
         self._buckets = None
+        self._reducer: Optional[BucketedGradReducer] = None     # built once: its side stream lives as long as the trainer
 
     def step(self, x_local: torch.Tensor, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
              global_batch: Optional[int] = None) -> torch.Tensor:
@@ -239,7 +319,11 @@ class DataParallelTrainer:
             if self._buckets is None:
                 self._buckets = plan_buckets(unet.grad_layout(), len(unet._cfg['dim_mults']), self.n_buckets)
             unet.grad_views(x_local.device)              # allocates grad_flat on first use
-            red = BucketedGradReducer(self.dist, unet.grad_flat, self._buckets, n, gb)
+            red = self._reducer
+            if red is None or red.flat.data_ptr() != unet.grad_flat.data_ptr():
+                red = self._reducer = BucketedGradReducer(self.dist, unet.grad_flat, self._buckets, n, gb, timing=self.timing)
+            else:
+                red.reset(n, gb)
             loss = self.dm.train_step_native(x_local, t=t, noise=noise, on_backward_group=red.on_group)
             red.finish()
         self.opt.step()
@@ -247,3 +331,12 @@ class DataParallelTrainer:
             loss = loss * (n / float(gb))
             self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM)
         return loss
+
+    def comm_report(self) -> dict:
+        """What one driver run of N > 1 ranks should show: the backend and world size torch.distributed
+        reports, and -- with timing=True -- the bucket / all-reduce / backward event times of the last step."""
+        rep = {'dist_backend': self.dist.get_backend() if self.dist is not None else None,
+               'world_size': self.dist.get_world_size() if self.dist is not None else 1, 'grad_buckets': self.n_buckets}
+        if self._reducer is not None:
+            rep.update(self._reducer.report())
+        return rep

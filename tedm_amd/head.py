@@ -223,11 +223,14 @@ def train_tail_supported(tail: Sequence[torch.nn.Module], c1: int) -> bool:
             and c3.kernel_size == (1, 1) and c3.in_channels == 32 and c3.out_channels == 1 and c3.bias is not None)
 
 
-def _bn_coeffs(part: Tensor, P: int, gamma: Tensor, beta: Tensor, eps: float):
-    """Per-block (sum, sumsq) partials [blocks][C][2] -> batch mean, biased variance, rstd and y = a x + b (fp64 reduction)."""
+def _bn_coeffs(part: Tensor, P: int, gamma: Tensor, beta: Tensor, eps: float, shift: Tensor):
+    """Per-block partials [blocks][C][2] = (sum, sumsq) of (x - shift) -> batch mean, biased variance, rstd and y = a x + b (fp64
+    reduction).  The kernels sum around `shift` (a per-channel estimate of the mean from the first pixels): E[x^2] - mean^2 from
+    fp32 sums of the raw values loses the variance of a channel with |mean| >> std; around the shift it does not."""
     s = part.double().sum(0)
-    mean = s[:, 0] / P
-    var = (s[:, 1] / P - mean * mean).clamp_min(0.0)
+    dm = s[:, 0] / P
+    mean = shift.double() + dm
+    var = (s[:, 1] / P - dm * dm).clamp_min(0.0)
     rstd = torch.rsqrt(var + eps)
     a = gamma.double() * rstd
     b = beta.double() - mean * a
@@ -252,16 +255,21 @@ class FusedTailTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(dev)
             part1 = torch.empty(nb, C1, 2, **f32)
-            _lib.check(L.tedm_head_train_stats1(h1.data_ptr(), P, C1, part1.data_ptr(), nb, st), 'tedm_head_train_stats1')
-            mean1, var1, rstd1, a1, b1 = _bn_coeffs(part1, P, g1.detach(), be1.detach(), eps1)
+            head_px = h1.view(P, C1)[:min(P, 256)]                                  # a few pixels: per-channel shifts for the statistics
+            r1h = torch.relu(head_px)
+            shift1 = r1h.mean(0).contiguous()
+            _lib.check(L.tedm_head_train_stats1(h1.data_ptr(), P, C1, shift1.data_ptr(), part1.data_ptr(), nb, st), 'tedm_head_train_stats1')
+            mean1, var1, rstd1, a1, b1 = _bn_coeffs(part1, P, g1.detach(), be1.detach(), eps1, shift1)
             w2m = w2.detach().reshape(32, C1).float().contiguous()
             w2t = w2m.t().contiguous()
             z2 = torch.empty(P, 32, **f32)
             part2 = torch.empty(nb, 32, 2, **f32)
+            bias2f = bias2.detach().float().contiguous()
+            shift2 = torch.relu((r1h * a1 + b1) @ w2t + bias2f).mean(0).contiguous()
             _lib.check(L.tedm_head_train_mid(h1.data_ptr(), P, C1, a1.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
-                                             bias2.detach().float().contiguous().data_ptr(), z2.data_ptr(), part2.data_ptr(), nb, st),
+                                             bias2f.data_ptr(), shift2.data_ptr(), z2.data_ptr(), part2.data_ptr(), nb, st),
                        'tedm_head_train_mid')
-            mean2, var2, rstd2, a2, b2 = _bn_coeffs(part2, P, g2.detach(), be2.detach(), eps2)
+            mean2, var2, rstd2, a2, b2 = _bn_coeffs(part2, P, g2.detach(), be2.detach(), eps2, shift2)
             w3v = w3.detach().reshape(32).float().contiguous()
             logits = torch.empty(B, 1, S, S2, **f32)
             _lib.check(L.tedm_head_train_out(z2.data_ptr(), P, a2.data_ptr(), b2.data_ptr(), w3v.data_ptr(),

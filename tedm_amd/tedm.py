@@ -160,15 +160,19 @@ def validate_head(config: Namespace, model, val_dl: Iterable, dist=None) -> Dict
     model.train(was)
     if hasattr(model, 'diffusion_model'):
         model.diffusion_model.eval()
-    out = {'val/loss': float(torch.cat(m['val/loss']).mean())}
-    for k in ('val/dice', 'val/precision', 'val/recall', 'val/dice_ensemble'):
-        out[k] = float(torch.cat(m[k]).nanmean())
-    if dist is not None:                                       # equal-sized validation shards: mean of rank means
+    # Means over ALL samples of all ranks, NaN samples ignored as the reference's nanmean over one device's samples does
+    # (trainers/train_baseline.py:146-161): per metric the ranks exchange (sum of the finite values, their count).  A mean of
+    # per-rank nanmeans would turn NaN as soon as one rank's shard has no positives.
+    sums = {}
+    for k in ('val/loss', 'val/dice', 'val/precision', 'val/recall', 'val/dice_ensemble'):
+        v = torch.cat(m[k]).double().flatten().cpu()
+        fin = torch.isfinite(v) if k != 'val/loss' else torch.ones_like(v, dtype=torch.bool)
+        sums[k] = (float(v[fin].sum()), float(fin.sum()))
+    if dist is not None:
         from . import dp
         dev = torch.device(config.device) if 'cuda' in str(config.device) else None
-        for k in out:
-            out[k] = dp.sum_over_ranks(dist, out[k], dev) / dist.get_world_size()
-    return out
+        sums = {k: (dp.sum_over_ranks(dist, a, dev), dp.sum_over_ranks(dist, c, dev)) for k, (a, c) in sums.items()}
+    return {k: (a / c if c > 0 else float('nan')) for k, (a, c) in sums.items()}
 
 
 def allreduce_head_grads_(dist, params) -> None:

@@ -66,6 +66,17 @@ class SinusoidalPosEmb(_Container):
         self.register_buffer('freqs', freqs.float(), persistent=False)
 
 
+class LearnedSinusoidalPosEmb(_Container):
+    """models/unet_model.py:96-114 (`learned_sinusoidal_cond=True`): cat(t, sin(2 pi t w), cos(2 pi t w)) with the learned
+    frequency vector `weights` (dim / 2); the arithmetic runs in `temb_kernel`, the gradient in `learned_sinusoid_bwd_kernel`."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        assert dim % 2 == 0
+        self.dim = dim
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
 class LayerNorm(_Container):
     """models/unet_model.py:52-61 (gain only)."""
 
@@ -180,6 +191,7 @@ class _UnetTrainFn(torch.autograd.Function):
         ctx.mask = [p.requires_grad for p in params]
         eps = unet.native_forward_train(x, timestep)
         ctx.generation = unet.tape_generation()         # the handle keeps ONE tape: a later forward overwrites it
+        unet._fire_tap_hooks_from_tape()                # forward hooks on ups[i][2] fire on this route too (datasetDM_model.py:50-53)
         return eps
 
     @staticmethod
@@ -195,9 +207,6 @@ class Unet(nn.Module):
                  learned_variance: bool = False, learned_sinusoidal_cond: bool = False,
                  learned_sinusoidal_dim: int = 16, **kwargs):
         super().__init__()
-        if learned_sinusoidal_cond:
-            raise NotImplementedError('learned_sinusoidal_cond=True is not on the TEDM hot path '
-                                      '(config.py never sets it) and has no HIP kernel')
         self.channels = channels
         init_dim = init_dim if init_dim is not None else dim
         dim_mults = tuple(int(m) for m in dim_mults)
@@ -205,9 +214,12 @@ class Unet(nn.Module):
         dims = [init_dim, *[dim * m for m in dim_mults]]
         in_out = list(zip(dims[:-1], dims[1:]))
         time_dim = dim * 4
-        self.learned_sinusoidal_cond = False
-        self.time_mlp = nn.Sequential(SinusoidalPosEmb(dim), nn.Linear(dim, time_dim), nn.GELU(),
-                                      nn.Linear(time_dim, time_dim))
+        self.learned_sinusoidal_cond = bool(learned_sinusoidal_cond)             # models/unet_model.py:278-292
+        if self.learned_sinusoidal_cond:
+            pos_emb, fourier_dim = LearnedSinusoidalPosEmb(learned_sinusoidal_dim), learned_sinusoidal_dim + 1
+        else:
+            pos_emb, fourier_dim = SinusoidalPosEmb(dim), dim
+        self.time_mlp = nn.Sequential(pos_emb, nn.Linear(fourier_dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
 
         def rb(a, b):
             return ResnetBlock(a, b, time_emb_dim=time_dim, groups=resnet_block_groups)
@@ -235,7 +247,8 @@ class Unet(nn.Module):
 
         # ---- native side -----------------------------------------------------------------
         self._cfg = dict(dim=dim, init_dim=init_dim, out_dim=self.out_dim, dim_mults=dim_mults, channels=channels,
-                         groups=resnet_block_groups, heads=4, dim_head=32)
+                         groups=resnet_block_groups, heads=4, dim_head=32,
+                         learned_sinusoidal_dim=int(learned_sinusoidal_dim) if learned_sinusoidal_cond else 0)
         # Two native handles, one per ROLE: 'infer' (forward / module_forward, packed for `precision`) and 'train'
         # (forward_train / backward, packed for `train_precision`, owns the tape and the data-gradient packs).  Each owns its
         # packed weights, so an eval / sampling / validation forward between a training forward and its backward can neither
@@ -311,6 +324,7 @@ class Unet(nn.Module):
         for i, m in enumerate(c['dim_mults']):
             cfg.dim_mults[i] = m
         cfg.channels, cfg.groups, cfg.heads, cfg.dim_head = c['channels'], c['groups'], c['heads'], c['dim_head']
+        cfg.learned_sinusoidal_dim = c['learned_sinusoidal_dim']
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(L.tedm_unet_create(C.byref(cfg), C.byref(h)), 'tedm_unet_create')
@@ -319,7 +333,8 @@ class Unet(nn.Module):
 
     def _native_tensors(self) -> Dict[str, Tensor]:
         sd = {k: v for k, v in self.named_parameters()}
-        sd['time_mlp.0.freqs'] = self.time_mlp[0].freqs
+        if not self.learned_sinusoidal_cond:
+            sd['time_mlp.0.freqs'] = self.time_mlp[0].freqs
         return sd
 
     def _prec_name(self, training: bool) -> str:
@@ -546,6 +561,24 @@ class Unet(nn.Module):
                 'tedm_unet_forward_train')
         return eps
 
+    def _taps_hooked(self) -> bool:
+        return any(len(lvl[2]._forward_hooks) or len(lvl[2]._forward_pre_hooks) for lvl in self.ups)
+
+    def _fire_tap_hooks_from_tape(self) -> None:
+        """Training / autograd route: the hooked tensors are what the tape keeps as the tail convs' inputs.  The hooks receive
+        DETACHED channels-last views into the training workspace (valid until the backward of this forward or the next training
+        forward; a hook that keeps one must copy it, as the reference's own `save_activations` does with .detach().cpu())."""
+        if not self._taps_hooked():
+            return
+        L = _lib.lib()
+        h = self._native['train'].handle
+        for i, lvl in enumerate(self.ups):
+            off, shp = C.c_size_t(), (C.c_int * 4)()
+            _lib.check(L.tedm_unet_tape_tap(h, i, C.byref(off), shp), 'tedm_unet_tape_tap')
+            b, hh, ww, c = list(shp)
+            tap = self._train_ws[off.value: off.value + 4 * b * hh * ww * c].view(torch.float32).view(b, hh, ww, c).permute(0, 3, 1, 2)
+            lvl[2](tap, _native_out=tap)
+
     def tape_generation(self) -> int:
         """Generation of the training tape the native handle holds (bumped by every `native_forward_train`)."""
         h = self._native['train'].handle
@@ -602,7 +635,7 @@ class Unet(nn.Module):
                 raise NotImplementedError('tedm_amd.Unet: gradients w.r.t. the input image are not computed')
             names, params = zip(*self.named_parameters())
             return _UnetTrainFn.apply(self, x, timestep, names, *params)
-        hooked = any(len(lvl[2]._forward_hooks) or len(lvl[2]._forward_pre_hooks) for lvl in self.ups)
+        hooked = self._taps_hooked()
         eps, taps = self.native_forward(x, timestep, want_taps=hooked)
         if hooked:
             for lvl, tap in zip(self.ups, taps):

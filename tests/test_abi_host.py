@@ -146,3 +146,21 @@ def test_workspace_sizing_is_host_only_and_monotonic(built_lib):
     assert L.tedm_unet_backward(h, C.c_void_p(8), C.c_void_p(8), 1 << 20, None) != 0
     assert b'tape' in L.tedm_last_error()
     L.tedm_unet_destroy(h)
+
+
+def test_learned_sinusoidal_cond_contract(golden_dir, built_lib):
+    """`Unet(learned_sinusoidal_cond=True)` (models/unet_model.py:96-114,278-285): the state-dict keys of the reference (the learned
+    frequency vector `time_mlp.0.weights`, a 17-input `time_mlp.1`), the native plan asking for exactly these tensors, and the
+    oracle reproducing the eps the reference computed (fixture: oracle/make_golden_ckpt.py --learned)."""
+    import numpy as np
+    import torch
+    from oracle import unet_ref as O
+    from tedm_amd import Unet, load_synth_weights
+    g = np.load(golden_dir / 'learned_sinusoid_d32_s32.npz')
+    m = Unet(32, dim_mults=(1, 2), channels=1, learned_sinusoidal_cond=True, learned_sinusoidal_dim=16)
+    assert sorted(m.state_dict()) == [str(k) for k in g['keys']]
+    assert m.time_mlp[1].in_features == int(g['fourier_in']) == 17 and tuple(m.time_mlp[0].weights.shape) == (8,)
+    load_synth_weights(m, seed=3)
+    w = {k: v.detach() for k, v in m.state_dict().items()}
+    eps = O.unet_forward(w, torch.from_numpy(g['x']), torch.from_numpy(g['t']), dim=32, dim_mults=(1, 2))
+    assert float((eps - torch.from_numpy(g['eps'])).norm() / torch.from_numpy(g['eps']).norm()) < 1e-6

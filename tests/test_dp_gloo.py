@@ -150,11 +150,23 @@ def _bucket_worker(rank, world, port, q):
     local_n, global_n = (3, 5) if rank == 0 else (2, 5)                    # ragged shards: scale by local_n / global_n
     single = dp.allreduce_grads_(dist, local.clone(), local_n, global_n)
     flat = local.clone()
-    red = dp.BucketedGradReducer(dist, flat, dp.plan_buckets(sizes, 4, 4), local_n, global_n)
+    red = dp.BucketedGradReducer(dist, flat, dp.plan_buckets(sizes, 4, 4), local_n, global_n, timing=True)
     for name in dp.backward_group_order(4):                                 # the sequence the native backward reports
         red.on_group(name)
     red.finish()
-    q.put((rank, bool(torch.equal(flat, single)), float(flat.double().sum())))
+    ok = bool(torch.equal(flat, single))
+    rep = red.report()                                                      # what one N > 1 driver run has to show
+    ok = ok and [b['last_group'] for b in rep['buckets']] == ['ups.1', 'ups.0', 'mid_block1', 'time_mlp']
+    ok = ok and sum(b['elements'] for b in rep['buckets']) == total and rep['backward_done_ms'] >= rep['buckets'][-1]['closed_ms']
+    ok = ok and all(b['allreduce_done_ms'] >= b['closed_ms'] and b['allreduce_gb_per_s'] > 0 for b in rep['buckets'])
+    # second step on the SAME reducer (one side stream / object for the trainer's lifetime): reset, same result
+    flat.copy_(local)
+    red.reset(local_n, global_n)
+    for name in dp.backward_group_order(4):
+        red.on_group(name)
+    red.finish()
+    ok = ok and bool(torch.equal(flat, single))
+    q.put((rank, ok, float(flat.double().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -172,3 +184,84 @@ def test_two_rank_gloo_bucketed_allreduce_is_bit_identical_to_single_buffer():
         assert p.exitcode == 0
     assert all(eq for _, eq, _ in res), res
     assert res[0][2] == res[1][2]                                           # both ranks hold the same reduced buffer
+
+
+def _failing_bucket_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from tedm_amd import dp
+    from tedm_amd.unet import Unet
+    dist = dp.init('gloo')
+    sizes = Unet(32).grad_layout()
+    flat = torch.ones(sum(n for _, n in sizes))
+    red = dp.BucketedGradReducer(dist, flat, dp.plan_buckets(sizes, 4, 4), 1, 2)
+    if rank == 1:                                                            # this rank's callback fails at its second bucket
+        real = red._reduce
+        def broken(name, lo, hi):
+            if name == 'ups.0':
+                raise ValueError('injected failure in the backward callback')
+            real(name, lo, hi)
+        red._reduce = broken
+    try:
+        for name in dp.backward_group_order(4):
+            red.on_group(name)
+        red.finish()
+        q.put((rank, 'finished'))
+    except BaseException as e:
+        q.put((rank, type(e).__name__ + ': ' + str(e)[:80]))
+
+
+def test_a_rank_failing_between_buckets_does_not_leave_its_peer_waiting():
+    """an exception inside the backward's mark callback is deferred to finish(); by then the failing rank has issued
+    fewer collectives than its peers.  It tears its process group down, so the peer's pending all-reduce FAILS (here: within
+    seconds on gloo) instead of waiting for the backend timeout."""
+    world, port = 2, 29641
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert 'injected failure' in res[1] or res[1].startswith('RuntimeError'), res
+    assert res[0] != 'finished', res                                        # the healthy rank got an error, not a silent hang / success
+
+
+def _validate_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from argparse import Namespace
+    from tedm_amd import dp, tedm
+    dist = dp.init('gloo')
+    model = torch.nn.Conv2d(1, 1, 1)
+    with torch.no_grad():
+        model.weight.fill_(4.0); model.bias.fill_(-2.0)                   # predicts x > 0.5
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(4, 1, 8, 8, generator=g)
+    y = (x > 0.5).float() if rank == 0 else torch.zeros(4, 1, 8, 8)       # rank 1's shard has NO positives: its recall / Dice are NaN per sample
+    if rank == 1:
+        x = x * 0.4                                                       # ... and no predicted positives either
+    out = tedm.validate_head(Namespace(device='cpu'), model, [(x, y)], dist)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_metrics_are_global_nanmeans_over_ranks():
+    """a rank whose validation shard has no positives yields NaN per-sample Dice / recall; the global metric must ignore
+    those samples (the reference's nanmean over all samples of one device), not become NaN."""
+    world, port = 2, 29647
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_validate_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                               # every rank reports the global value
+    for k in ('val/loss', 'val/dice', 'val/recall', 'val/dice_ensemble'):
+        assert res[0][k] == res[0][k], (k, res[0])                        # not NaN
+    assert res[0]['val/dice'] == 1.0 and res[0]['val/recall'] == 1.0      # rank 0's four perfect samples; rank 1's NaN samples ignored

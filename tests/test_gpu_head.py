@@ -115,3 +115,26 @@ def test_fused_training_tail_matches_torch_modules(dev, shape):
         assert rl(f['grads'][k], t['grads'][k]) < 5e-4, k
     for k in t['bufs']:
         assert rl(f['bufs'][k], t['bufs'][k]) < 1e-5, k
+
+
+def test_fused_training_tail_keeps_the_variance_of_strongly_offset_channels(dev):
+    """relu(h1) with mean ~50 and std ~0.1 per channel (a large first-layer bias).  E[x^2] - mean^2 from fp32 sums of
+    the raw values loses that variance (50^2 = 2500 against 0.01: 5.4 digits of 7); the kernels sum around a per-channel shift
+    taken from the first pixels, so BatchNorm1's statistics -- and with them the logits and the running variance -- match torch's."""
+    from tedm_amd.head import fused_tail_train
+    nn = torch.nn
+    B, S, C1 = 2, 48, 128
+    g = torch.Generator().manual_seed(11)
+    h_nhwc = (50.0 + 0.1 * torch.randn(B, S, S, C1, generator=g)).to(dev)
+    res = {}
+    for kind in ('torch', 'fused'):
+        torch.manual_seed(5)
+        tail = nn.Sequential(nn.ReLU(), nn.BatchNorm2d(C1), nn.Conv2d(C1, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1)).to(dev).train()
+        h_nchw = h_nhwc.clone().permute(0, 3, 1, 2)
+        with torch.no_grad():
+            out = fused_tail_train(list(tail), h_nchw) if kind == 'fused' else tail(h_nchw)
+        res[kind] = (out.double(), tail[1].running_var.double().clone(), tail[1].running_mean.double().clone())
+    rl = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    print(f'offset channels: logits {rl(res["fused"][0], res["torch"][0]):.2e}, running_var {rl(res["fused"][1], res["torch"][1]):.2e}')
+    assert rl(res['fused'][1], res['torch'][1]) < 1e-4 and rl(res['fused'][2], res['torch'][2]) < 1e-6
+    assert rl(res['fused'][0], res['torch'][0]) < 1e-3

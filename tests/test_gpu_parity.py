@@ -570,6 +570,31 @@ def test_final_block_tail_folded_with_final_conv(lib, dev, prec):
         assert not torch.equal(e1, e0)
 
 
+def test_final_fold_with_three_output_channels(lib, dev):
+    """out_dim = 3 (channels = 3, e.g. an RGB model): the folded final pass reads one fold row per output channel -- rows o >= 1
+    were only 4-byte aligned for its 16-byte loads before the row stride was padded.  Against the oracle and
+    against the unfolded kernels."""
+    from oracle import unet_ref as O
+    from tedm_amd import Unet, _lib, load_synth_weights
+    m = Unet(64, dim_mults=(1, 2), channels=3)
+    load_synth_weights(m, seed=9)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(31)
+    x, t = torch.randn(2, 3, 32, 32, generator=g), torch.tensor([5, 900])
+    ref = O.unet_forward(oracle_weights(m), x, t, dim=64, dim_mults=(1, 2))
+    res = {}
+    try:
+        for mode in (1, 0):
+            _lib.check(lib.tedm_set_tuning(b'final_fuse', mode), 'tune')
+            with torch.no_grad():
+                res[mode] = m(x.to(dev), t.to(dev))
+    finally:
+        lib.tedm_set_tuning(b'final_fuse', 1)
+    assert tuple(res[1].shape) == (2, 3, 32, 32)
+    assert rel(res[1], ref) < 1e-4 and rel(res[0], ref) < 1e-4 and rel(res[1], res[0]) < 1e-4
+    assert not torch.equal(res[1], res[0])
+
+
 def test_vs_oracle_ragged_shape(dev, unet64):
     """B=3, 96x72 (not a power of two, H != W) against the oracle incl. module trace."""
     from oracle import unet_ref as O
@@ -599,6 +624,31 @@ def test_forward_hooks_fire(dev, golden_dir, unet64):
     assert sorted(seen) == [0, 1, 2, 3]
     for i in range(4):
         assert rel(seen[i][:, ::4, ::2, ::2], g[f'tap{i}_sub']) < EPS_GATE
+
+
+def test_forward_hooks_fire_on_the_autograd_route(dev, golden_dir, unet64):
+    """The same hooks when Unet.forward takes the differentiable route (grad enabled, module in train mode: any hooked caller
+    that is not under torch.no_grad(), e.g. the shared-weights TEDM training when the backbone is not frozen): the hooked tensors
+    come from the training tape and match the reference taps; the backward still runs afterwards."""
+    g = np.load(golden_dir / 'eps_d64_s64.npz')
+    seen = {}
+    handles = [lvl[2].register_forward_hook(lambda m, inp, out, i=i: seen.__setitem__(i, out.detach().cpu()))
+               for i, lvl in enumerate(unet64.ups)]
+    was_training = unet64.training
+    try:
+        unet64.train()
+        eps = unet64(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev))
+        assert eps.grad_fn is not None
+        eps.sum().backward()
+    finally:
+        for h in handles:
+            h.remove()
+        unet64.train(was_training)
+        unet64.zero_grad(set_to_none=True)
+    assert sorted(seen) == [0, 1, 2, 3]
+    for i in range(4):
+        assert rel(seen[i][:, ::4, ::2, ::2], g[f'tap{i}_sub']) < EPS_GATE
+    assert rel(eps, g['eps']) < EPS_GATE
 
 
 def test_extract_features_vs_golden(dev, golden_dir):

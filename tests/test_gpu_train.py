@@ -289,3 +289,24 @@ def test_gradients_at_the_minimum_image_size(dev):
     m(x.to(dev), t.to(dev)).backward(R.to(dev))
     worst = max((rel(p.grad, gref[k]), k) for k, p in m.named_parameters())
     assert worst[0] < GRAD_TOL, worst
+
+
+def test_learned_sinusoidal_cond_forward_and_gradients_vs_reference(dev, golden_dir):
+    """`learned_sinusoidal_cond=True` (models/unet_model.py:96-114,278-285) on the HIP path: eps against the eps THE REFERENCE
+    computed (oracle/make_golden_ckpt.py --learned), and the gradient of the learned frequency vector (plus the 17-input
+    time_mlp.1 behind it) against the reference's autograd."""
+    from tedm_amd import Unet, load_synth_weights
+    g = np.load(golden_dir / 'learned_sinusoid_d32_s32.npz')
+    m = Unet(32, dim_mults=(1, 2), channels=1, learned_sinusoidal_cond=True, learned_sinusoidal_dim=16)
+    load_synth_weights(m, seed=3)
+    x, t, R = (torch.from_numpy(g[k]).to(dev) for k in ('x', 't', 'R'))
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        e_inf = rel(m(x, t), g['eps'])
+    m.train()
+    eps = m(x, t)
+    eps.backward(R)
+    e_tr = rel(eps, g['eps'])
+    gw, g1 = rel(m.time_mlp[0].weights.grad, g['grad_weights']), rel(m.time_mlp[1].weight.grad, g['grad_mlp1'])
+    print(f'learned sinusoid: eps vs reference {e_inf:.2e} (inference) {e_tr:.2e} (training forward); d weights {gw:.2e}, d time_mlp.1 {g1:.2e}')
+    assert e_inf < 1e-4 and e_tr < 1e-4 and gw < GRAD_TOL and g1 < GRAD_TOL

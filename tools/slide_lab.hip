@@ -47,6 +47,34 @@ namespace g3 {
 #undef SL_GAPMODE
 #undef SL_ABL
 }
+namespace f2 {
+#define SL_ABL 13
+#define SL_FILL 2
+#include "conv_slide.hip"
+#undef SL_FILL
+#undef SL_ABL
+}
+namespace f4 {
+#define SL_ABL 13
+#define SL_FILL 4
+#include "conv_slide.hip"
+#undef SL_FILL
+#undef SL_ABL
+}
+namespace f6 {
+#define SL_ABL 13
+#define SL_FILL 6
+#include "conv_slide.hip"
+#undef SL_FILL
+#undef SL_ABL
+}
+namespace f8 {
+#define SL_ABL 13
+#define SL_FILL 8
+#include "conv_slide.hip"
+#undef SL_FILL
+#undef SL_ABL
+}
 namespace x5 {
 #define SL_ABL 5
 #include "conv_slide.hip"
@@ -136,14 +164,15 @@ int main(int argc, char** argv) {
         else vs = {{"slide rows 256", v0::conv_slide_launch, 256, &v0::g_conv_slide_rows},
                              {"slide rows 128", v0::conv_slide_launch, 128, &v0::g_conv_slide_rows},
 #ifdef SL_LAB_EXTRA
-                             {"no stores, enc @h0", g1::conv_slide_launch, 256, &g1::g_conv_slide_rows},
-                             {"no stores, enc @h1", g2::conv_slide_launch, 256, &g2::g_conv_slide_rows},
-                             {"no stores, enc @f4", g3::conv_slide_launch, 256, &g3::g_conv_slide_rows},
                              {"no encoder, rows 256", x1::conv_slide_launch, 256, &x1::g_conv_slide_rows},
                              {"no stores, rows 256", x2::conv_slide_launch, 256, &x2::g_conv_slide_rows},
                              {"neither, rows 256", x3::conv_slide_launch, 256, &x3::g_conv_slide_rows},
                              {"mfma + lds reads only", x5::conv_slide_launch, 256, &x5::g_conv_slide_rows},
                              {"mfma only", x13::conv_slide_launch, 256, &x13::g_conv_slide_rows},
+                             {"mfma only + 2 VALU/gap", f2::conv_slide_launch, 256, &f2::g_conv_slide_rows},
+                             {"mfma only + 4 VALU/gap", f4::conv_slide_launch, 256, &f4::g_conv_slide_rows},
+                             {"mfma only + 6 VALU/gap", f6::conv_slide_launch, 256, &f6::g_conv_slide_rows},
+                             {"mfma only + 8 VALU/gap", f8::conv_slide_launch, 256, &f8::g_conv_slide_rows},
 #endif
         };
         std::vector<std::vector<float>> t(vs.size());
