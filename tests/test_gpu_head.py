@@ -120,21 +120,22 @@ def test_fused_training_tail_matches_torch_modules(dev, shape):
 def test_fused_training_tail_keeps_the_variance_of_strongly_offset_channels(dev):
     """relu(h1) with mean ~50 and std ~0.1 per channel (a large first-layer bias).  E[x^2] - mean^2 from fp32 sums of
     the raw values loses that variance (50^2 = 2500 against 0.01: 5.4 digits of 7); the kernels sum around a per-channel shift
-    taken from the first pixels, so BatchNorm1's statistics -- and with them the logits and the running variance -- match torch's."""
+    taken from the first pixels.  Reference: the same torch layers in float64 (torch's own fp32 BatchNorm is 1.3e-2 off them on
+    this input, measured; the kernels 9e-6)."""
     from tedm_amd.head import fused_tail_train
     nn = torch.nn
     B, S, C1 = 2, 48, 128
     g = torch.Generator().manual_seed(11)
     h_nhwc = (50.0 + 0.1 * torch.randn(B, S, S, C1, generator=g)).to(dev)
     res = {}
-    for kind in ('torch', 'fused'):
+    for kind in ('torch64', 'fused'):
         torch.manual_seed(5)
         tail = nn.Sequential(nn.ReLU(), nn.BatchNorm2d(C1), nn.Conv2d(C1, 32, 1), nn.ReLU(), nn.BatchNorm2d(32), nn.Conv2d(32, 1, 1)).to(dev).train()
         h_nchw = h_nhwc.clone().permute(0, 3, 1, 2)
         with torch.no_grad():
-            out = fused_tail_train(list(tail), h_nchw) if kind == 'fused' else tail(h_nchw)
-        res[kind] = (out.double(), tail[1].running_var.double().clone(), tail[1].running_mean.double().clone())
+            out = fused_tail_train(list(tail), h_nchw) if kind == 'fused' else tail.double()(h_nchw.double())
+        res[kind] = (out.double(), tail[1].running_var.double().clone(), tail[1].running_mean.double().clone(), tail[4].running_var.double().clone())
     rl = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
-    print(f'offset channels: logits {rl(res["fused"][0], res["torch"][0]):.2e}, running_var {rl(res["fused"][1], res["torch"][1]):.2e}')
-    assert rl(res['fused'][1], res['torch'][1]) < 1e-4 and rl(res['fused'][2], res['torch'][2]) < 1e-6
-    assert rl(res['fused'][0], res['torch'][0]) < 1e-3
+    errs = [rl(a, b) for a, b in zip(res['fused'], res['torch64'])]
+    print('offset channels vs float64 layers: logits %.2e, running_var1 %.2e, running_mean1 %.2e, running_var2 %.2e' % tuple(errs))
+    assert errs[0] < 1e-4 and errs[1] < 1e-5 and errs[2] < 1e-6 and errs[3] < 1e-5
