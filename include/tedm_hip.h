@@ -175,6 +175,19 @@ int tedm_unet_set_backward_callback(tedm_unet* h, tedm_backward_mark_fn fn, void
 int tedm_l1_loss(const float* eps, const float* target, const int64_t* t, const float* p2w, int T, int B,
                  long long chw, float* grad, float* scratch, float* loss, void* stream);
 
+/* One ancestral sampling step behind the UNet forward (models/diffusion_model.py:205-267: model_predictions -> p_mean_variance with
+ * the per-sample 99.5 % dynamic thresholding -> q_posterior -> sample_timestep) as one kernel, one workgroup per sample.
+ *   model_out : what the UNet returned, (B, chw); objective 0: it is eps ('pred_noise'), 1: it is x0 ('pred_x_start')
+ *   noise     : NULL (no noise term: p_mean_variance alone) or (B, chw); ignored for samples with t = 0
+ *   clip      : `clip_denoised`; k_lo / w: floor and fractional part of q * (chw - 1) evaluated in fp32 as torch.quantile does
+ *   outputs   : x0 (B, chw) clipped and normalised, mean (may be NULL), x_prev (may be NULL), s_out [B] thresholds (may be NULL)
+ * The five coefficient tables are the module's buffers (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1/2, posterior_log_variance_clipped), T entries each. */
+int tedm_sampler_step(const float* x_t, const float* model_out, const int64_t* t, const float* noise, const float* sqrt_recip_acp,
+                      const float* sqrt_recipm1_acp, const float* coef1, const float* coef2, const float* logvar, int T, int B,
+                      long long chw, int objective, int clip, long long k_lo, float w, float* x0, float* mean, float* x_prev,
+                      float* s_out, void* stream);
+
 /* ---- stand-alone sub-module forward --------------------------------------------------------------------------------------
  * The reference's Unet subclasses (models/global_local_cl.py:33-47,75-104) call `block(x, t)` and `attn(x)` on the modules of
  * `self.downs / mid_* / self.ups` directly.  `module` is the state-dict prefix of a ResnetBlock ("downs.0.0", "mid_block1",

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'tedm_unet_forward_train': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, C.c_int]),
     'tedm_unet_backward': (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     'tedm_unet_backward_gen': (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_longlong]),
+    'tedm_sampler_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_longlong,
+                                    C.c_float, _P, _P, _P, _P, _P]),
     'tedm_unet_tape_generation': (C.c_longlong, [_P]),
     'tedm_unet_tape_tap': (C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     'tedm_unet_set_backward_callback': (C.c_int, [_P, _P, _P]),

@@ -17,7 +17,7 @@ ROOT = PKG.parent
 CSRC = PKG / 'csrc'
 OBJ = CSRC / 'build'
 LIB = PKG / 'libtedm_hip.so'
-SOURCES = ['conv_igemm_p0.hip', 'conv_igemm_p1.hip', 'conv_igemm_p2.hip', 'conv_igemm_p3.hip', 'conv_igemm_p4.hip', 'conv_igemm.hip', 'conv_slide.hip', 'conv_slide128.hip', 'pack.hip', 'elementwise.hip', 'attention.hip', 'linattn_fused.hip', 'wgrad.hip', 'wgrad_mfma.hip', 'backward.hip', 'head_train.hip', 'attention_bwd.hip', 'unet_host.hip']
+SOURCES = ['conv_igemm_p0.hip', 'conv_igemm_p1.hip', 'conv_igemm_p2.hip', 'conv_igemm_p3.hip', 'conv_igemm_p4.hip', 'conv_igemm.hip', 'conv_slide.hip', 'conv_slide128.hip', 'pack.hip', 'elementwise.hip', 'sampler.hip', 'attention.hip', 'linattn_fused.hip', 'wgrad.hip', 'wgrad_mfma.hip', 'backward.hip', 'head_train.hip', 'attention_bwd.hip', 'unet_host.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 

@@ -187,31 +187,62 @@ class DiffusionModel(nn.Module):
         mean = _take(self.posterior_mean_coef1, t, x_t.shape) * x_start + _take(self.posterior_mean_coef2, t, x_t.shape) * x_t
         return mean, _take(self.posterior_log_variance_clipped, t, x_t.shape)
 
+    def _sampler_step_native(self, x_t: Tensor, t: Tensor, model_out: Tensor, noise: Optional[Tensor], clip_denoised: bool,
+                             want_mean: bool, want_prev: bool):
+        """Everything of one reverse step behind the UNet forward -- x0 from the prediction, the per-sample 99.5 % dynamic
+        threshold (an exact radix SELECT of the two order statistics torch.quantile interpolates, not a sort), clip / normalise,
+        posterior mean, noise term -- as ONE HIP kernel (tedm_sampler_step, csrc/sampler.hip).  Returns (x0, mean, x_prev)."""
+        import numpy as np
+        if self.objective == 'pred_noise':
+            objective = 0
+        elif self.objective in ('pred_x_start', 'pred_x_0'):
+            objective = 1
+        else:
+            raise ValueError(f'unknown objective {self.objective}')
+        B = x_t.shape[0]
+        chw = x_t[0].numel()
+        ranks = np.float32(self.dynamic_threshold_percentile) * np.float32(chw - 1)       # torch.quantile: q * (n - 1) in the input dtype
+        k_lo = int(np.floor(ranks))
+        w = float(np.float32(ranks - np.float32(k_lo)))
+        dev = x_t.device
+        xt = x_t.detach().float().contiguous()
+        mo = model_out.detach().float().contiguous()
+        tt = t.detach().to(device=dev, dtype=torch.long).contiguous()
+        x0 = torch.empty_like(xt)
+        mean = torch.empty_like(xt) if want_mean else None
+        prev = torch.empty_like(xt) if want_prev else None
+        nz = noise.detach().float().contiguous() if noise is not None else None
+        p = lambda v: None if v is None else v.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tedm_sampler_step(
+                xt.data_ptr(), mo.data_ptr(), tt.data_ptr(), p(nz), self.sqrt_recip_alphas_cumprod.data_ptr(),
+                self.sqrt_recipm1_alphas_cumprod.data_ptr(), self.posterior_mean_coef1.data_ptr(), self.posterior_mean_coef2.data_ptr(),
+                self.posterior_log_variance_clipped.data_ptr(), int(self.timesteps), B, chw, objective, 1 if clip_denoised else 0, k_lo, w,
+                x0.data_ptr(), p(mean), p(prev), None, torch.cuda.current_stream(dev).cuda_stream), 'tedm_sampler_step')
+        return x0, mean, prev
+
     def p_mean_variance(self, x_t: Tensor, t: Tensor, clip_denoised: bool = True, cond: Optional[Tensor] = None):
-        """diffusion_model.py:221-235 (per-sample percentile dynamic thresholding)."""
-        _, x0 = self.model_predictions(x_t, t, cond=cond)
-        if clip_denoised:
-            s = torch.quantile(x0.flatten(1).abs(), self.dynamic_threshold_percentile, dim=1)
-            s = torch.clamp(s, min=1.0)[:, None, None, None]
-            x0 = torch.clip(x0, -s, s) / s
-        mean, logvar = self.q_posterior(x0, x_t, t)
-        return mean, logvar, x0
+        """diffusion_model.py:221-235 (per-sample percentile dynamic thresholding); on a GPU tensor the arithmetic behind the
+        UNet forward is `_sampler_step_native`."""
+        if not x_t.is_cuda:
+            raise RuntimeError('tedm_amd.DiffusionModel runs on a ROCm GPU only: there is no CPU fallback')
+        out = self.model(x_t, t, cond)
+        x0, mean, _ = self._sampler_step_native(x_t, t, out, None, clip_denoised, True, False)
+        return mean, _take(self.posterior_log_variance_clipped, t, x_t.shape), x0
 
     @torch.no_grad()
     def sample_timestep(self, x_t: Tensor, t: int, cond: Optional[Tensor] = None) -> Tensor:
         """diffusion_model.py:205-219."""
         bt = torch.full((x_t.shape[0],), t, device=x_t.device, dtype=torch.long)
-        mean, logvar, _ = self.p_mean_variance(x_t, bt, cond=cond)
-        noise = torch.randn_like(x_t) if t > 0 else 0.
-        return mean + (0.5 * logvar).exp() * noise
+        return self._sample_step_tensor(x_t, bt, cond)
 
     # -- whole reverse chain (trainers/utils.py:62-98 `sample_plot_image` without the plotting) -------------
     def _sample_step_tensor(self, x_t: Tensor, bt: Tensor, cond: Optional[Tensor] = None) -> Tensor:
-        """`sample_timestep` with the timestep as a device tensor (no host branch on t, so the step can be
-        captured in a hipGraph): the noise term is masked where t == 0 instead of being skipped."""
-        mean, logvar, _ = self.p_mean_variance(x_t, bt, cond=cond)
-        noise = torch.randn_like(x_t) * (bt > 0).to(x_t.dtype).view(-1, 1, 1, 1)
-        return mean + (0.5 * logvar).exp() * noise
+        """`sample_timestep` with the timestep as a device tensor (no host branch on t, so the step can be captured in a hipGraph):
+        UNet forward, one torch.randn_like, one kernel for the rest (the noise term is dropped inside it where t == 0)."""
+        out = self.model(x_t, bt, cond)
+        noise = torch.randn_like(x_t, dtype=torch.float32)
+        return self._sampler_step_native(x_t, bt, out, noise, True, False, True)[2]
 
     @torch.no_grad()
     def sample(self, batch: int, img_size: int, channels: Optional[int] = None, cond: Optional[Tensor] = None,

@@ -615,6 +615,29 @@ class Unet(nn.Module):
                 raise errs[0]
         return self._grad_views
 
+    @torch.no_grad()
+    def fp16_range_report(self, x: Tensor, timestep: Optional[Tensor] = None, limit: float = 65504.0) -> Dict[str, float]:
+        """max |activation| of every traced module output on this input, computed with the fp32-range arithmetic (bf16x3).
+
+        The fast inference mode `f16f4` carries the convolution operands as fp16 (+ fp4 corrections): an activation beyond
+        +-65504 SATURATES there and everything downstream is wrong without any error (measured: a model whose residual stream
+        reaches 3e5 gives eps 0.87 off under f16f4 and 6e-5 under bf16x3, profiles/r04_eps_margin_trained.txt).  Networks with
+        a sane initialisation stay orders of magnitude below the limit; call this once per checkpoint on a representative batch.
+        Raises if `precision == 'f16f4'` and any module exceeds `limit` / 2."""
+        keep = self.precision
+        try:
+            self.precision = 'bf16x3'
+            self.native_forward(x, timestep, trace=True)
+            rep = {k: float(v.abs().max()) for k, v in self.last_trace.items()}
+        finally:
+            self.precision = keep
+        worst = max(rep.values()) if rep else 0.0
+        if keep == 'f16f4' and worst > limit / 2:
+            k = max(rep, key=rep.get)
+            raise OverflowError(f"precision 'f16f4' cannot carry this model: |activation| reaches {worst:.3g} at {k} (fp16 operands saturate at "
+                                f"{limit:g}); use precision='bf16x3'")
+        return rep
+
     def _read_trace(self) -> Dict[str, Tensor]:
         L = _lib.lib()
         out = {}

@@ -17,9 +17,11 @@ EPS_GATE = 1e-3          # BASELINE.json north_star: eps within 1e-3 rel (fp32 C
 KERNEL_TOL = 5e-5        # single conv, bf16x3 (operand error ~2^-17)
 F4_TOL = 2e-4            # single conv, f16f4: fp16 main product + fp4 cross terms (operand error ~2^-14)
 MODULE_TOL = 2e-4        # per-module trace, bf16x3
-MODE_TOL = {'bf16x3': dict(module=MODULE_TOL, eps=EPS_GATE / 10), 'f16f4': dict(module=2e-3, eps=EPS_GATE / 2)}
+MODE_TOL = {'bf16x3': dict(module=MODULE_TOL, eps=EPS_GATE / 10), 'f16f4': dict(module=1.5e-3, eps=EPS_GATE / 2)}
 # f16f4 module tolerance: intermediate tensors of the deep levels carry the single-fp16-product error of their ResnetBlock convs
-# (measured up to 1.4e-3 on mid_block2 of the 16x16 trace, where those levels are 2x2 pixels); the gate applies to eps
+# (measured up to 1.4e-3 on mid_block2 of the 16x16 trace with synthetic weights, where those levels are 2x2 pixels; on weights
+# trained from torch's default initialisation the worst module of a 64x64 trace is 1.1e-4, profiles/r04_eps_margin_trained.txt);
+# the gate applies to eps.  The trace tests print their worst module.
 
 
 def mtol(m):
@@ -438,12 +440,14 @@ def test_module_trace_mini_vs_golden(dev, golden_dir, prec):
     with torch.no_grad():
         eps, _ = m.native_forward(torch.from_numpy(g['x_t']).to(dev), torch.from_numpy(g['t']).to(dev), trace=True)
     names = [k[2:] for k in g.files if k.startswith('m:')]
-    bad = []
+    bad, worst = [], (0.0, '')
     for nm in names:
         assert nm in m.last_trace, f'{nm} missing from native trace {sorted(m.last_trace)}'
         e = rel(m.last_trace[nm], g['m:' + nm])
+        worst = max(worst, (e, nm))
         if not e < mtol(m):
             bad.append((nm, e))
+    print(f'module trace 16x16 {prec}: worst module {worst[1]} {worst[0]:.2e} (tolerance {mtol(m):.1e}), eps {rel(eps, g["eps"]):.2e}')
     assert not bad, bad
     assert rel(eps, g['eps']) < mtol(m)
 
