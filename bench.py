@@ -62,18 +62,23 @@ def host_cores() -> int:
 def pmc_traffic(kernel: str):
     """HBM-side bytes per launch of `kernel` from the newest committed PMC summary (tools/pmc_traffic.py:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
+    return pmc_traffic_with_source(kernel)[0]
+
+
+def pmc_traffic_with_source(kernel: str):
+    """(bytes per launch, name of the profiles/ file they come from) -- the bench line names its source"""
     files = sorted((ROOT / 'profiles').glob('*pmc_traffic.json'))
     if not files:
-        return None
+        return None, None
     try:
         ks = json.loads(files[-1].read_text())['kernels']
     except Exception:
-        return None
+        return None, None
     # rocprof prints every template argument; the library's label omits the trailing QIO = 0 of conv_igemm_kernel
     for name in (kernel, kernel[:-1] + ',0>' if kernel.endswith('>') else kernel):
         if name in ks:
-            return ks[name].get('hbm_bytes_per_launch')
-    return None
+            return ks[name].get('hbm_bytes_per_launch'), files[-1].name
+    return None, files[-1].name
 
 
 def bench_extract(args, dm, dp, dist, dev, world, rank, x0, noise):
@@ -425,7 +430,7 @@ def main() -> None:
                 'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': name,
                 'achieved': round(gbs if hbm_bound else achieved, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
-                'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(name),
+                'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic_with_source(name)[0], 'traffic_source': pmc_traffic_with_source(name)[1],
                 # `achieved`/`frac` of an HBM-bound kernel count the bytes of THIS build's storage (fp32 activations: 4 B per element
                 # of SURVEY 8d's (Cin+Cout)*HW); the same elements at the survey's bf16 convention (2 B) and the MFMA-side fraction
                 # are given next to it so that rounds stay comparable whatever the storage format

@@ -221,10 +221,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
     const int xlane = ct * 8192 + lane * 16;                    // this lane's slot in an exchange buffer
 #define S2_SCHED() __builtin_amdgcn_sched_barrier(0)
 
-    // one band's MFMAs (108) with `between(MFMA ordinal u)` called behind each; `slot_r`: ring slot of the band's first halo row
+    // Operand fragments of a group (chunk of the half, tap column, halo row), read SL_PF groups ahead of their MFMAs.  The first
+    // SL_PF (= 2) groups of a band read halo rows 0 and 1, which the PREVIOUS band already used as its rows 2 and 3: they are
+    // issued in front of the band's barrier (`band_prefetch`), so the first MFMAs behind it find their operands landed.
     f32x16 acc[2];
-    auto band_mfmas = [&](int slot_r, int y_first, auto&& between) __attribute__((always_inline)) {
-        int abase[4], sbase[4];
+    constexpr int NB = SL_PF + 1;
+    static_assert(SL_PF <= 2, "groups prefetched in front of the barrier must read halo rows 0 and 1 only");
+    u32x4 fa0[NB], fa1[NB], faq[NB];
+    int fas[NB];
+    int abase[4], sbase[4];
+    auto read_group = [&](auto G) __attribute__((always_inline)) {
+        constexpr int g = decltype(G)::value;                    // 0..23
+        constexpr int c = g / 12, kx = (g / 4) % 3, p = g % 4;
+        constexpr int off = c * SL_SEG + kx * SL_PST;
+        fas[g % NB] = *(const int*)(smem + sbase[p] + off);
+        S2_SCHED();
+        faq[g % NB] = *(const u32x4*)(smem + abase[p] + off + 64);
+        S2_SCHED();
+        fa1[g % NB] = *(const u32x4*)(smem + abase[p] + off + 32);
+        S2_SCHED();
+        fa0[g % NB] = *(const u32x4*)(smem + abase[p] + off);
+        S2_SCHED();
+    };
+    // `slot_r`: ring slot of the band's first halo row, `y_first` its image row
+    auto band_prefetch = [&](int slot_r, int y_first) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int y = y_first + p;
@@ -232,23 +252,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
             abase[p] = lane_a + off;
             sbase[p] = lane_s + off;
         }
-        constexpr int NB = SL_PF + 1;
-        u32x4 fa0[NB], fa1[NB], faq[NB];
-        int fas[NB];
-        auto read_group = [&](auto G) __attribute__((always_inline)) {
-            constexpr int g = decltype(G)::value;                // 0..23: chunk of the half, tap column, halo row
-            constexpr int c = g / 12, kx = (g / 4) % 3, p = g % 4;
-            constexpr int off = c * SL_SEG + kx * SL_PST;
-            fas[g % NB] = *(const int*)(smem + sbase[p] + off);
-            S2_SCHED();
-            faq[g % NB] = *(const u32x4*)(smem + abase[p] + off + 64);
-            S2_SCHED();
-            fa1[g % NB] = *(const u32x4*)(smem + abase[p] + off + 32);
-            S2_SCHED();
-            fa0[g % NB] = *(const u32x4*)(smem + abase[p] + off);
-            S2_SCHED();
-        };
         sl_for<SL_PF>([&](auto G) __attribute__((always_inline)) { read_group(G); });
+    };
+    // one band's MFMAs (108) with `between(MFMA ordinal u)` called behind each
+    auto band_mfmas = [&](auto&& between) __attribute__((always_inline)) {
         S2_SCHED();
         sl_for<24>([&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;
@@ -299,10 +306,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
         __builtin_amdgcn_s_waitcnt(sl_vmcnt_imm(0));
         __syncthreads();
         int slot_e = 4, slot_r = 0;
+        band_prefetch(0, y0 - 1);
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
             batch_rows(slot_e, y0 - 1 + 2 * b + 6);
-            band_mfmas(slot_r, y0 - 1 + 2 * b, [&](auto U) __attribute__((always_inline)) {
+            band_mfmas([&](auto U) __attribute__((always_inline)) {
                 constexpr int u = decltype(U)::value;
                 if constexpr (u < 6 * 16) stage(KH{}, U, std::integral_constant<int, s2_vm_after(1, u / 16, ST)>{});
             });
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
                     *(f32x4*)(xb + (ml * 4 + q4) * 1024) = v;
                 }
             slot_e = wrap(slot_e + 2); slot_r = wrap(slot_r + 2);
+            band_prefetch(slot_r, y0 - 1 + 2 * b + 2);
             __syncthreads();
         }
         __syncthreads();                                         // (pairs with the barrier in front of the other role's tail)
@@ -333,6 +342,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
         __builtin_amdgcn_s_waitcnt(sl_vmcnt_imm(0));
         __syncthreads();
         int slot_e = 4, slot_r = 0;
+        band_prefetch(0, y0 - 1);
         float pend[2][16];                                       // this wave's own partial sums of the previous band
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml)
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
             orow = a.out + ((size_t)(n * H + oyp) * W + tx * 32) * 64;
             xb = smem + S2_XCH + ((b + 1) & 1) * 16384 + xlane;
             if ((oyp & 2) == 0) { s1 = 0.f; s2 = 0.f; }
-            band_mfmas(slot_r, y0 - 1 + 2 * b, [&](auto U) __attribute__((always_inline)) {
+            band_mfmas([&](auto U) __attribute__((always_inline)) {
                 constexpr int u = decltype(U)::value;
                 if constexpr (u < 3 * 16) stage(KH{}, U, std::integral_constant<int, s2_vm_after(0, u / 16, ST)>{});
                 if constexpr (u % 3 == 1 && u / 3 < 32) epi_value(std::integral_constant<int, u / 3>{});
@@ -375,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide128_kernel(ConvArgs a, in
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pend[ml][i] = acc[ml][i];
             slot_e = wrap(slot_e + 2); slot_r = wrap(slot_r + 2);
+            band_prefetch(slot_r, y0 - 1 + 2 * b + 2);
             __syncthreads();
         }
         // the last band

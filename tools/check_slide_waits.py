@@ -38,10 +38,11 @@ def split_ops(line):
     return op, toks
 
 
-def band_loops(asm):
-    """[(kernel name, [instructions of its largest MFMA block])]"""
+def band_loops(asm, kernel):
+    """[(kernel name, [instructions of a band loop])]: every basic block with >= 100 MFMAs (conv3x3_slide128_kernel has two,
+    one per wave role)"""
     out = []
-    for m in re.finditer(r'^(_ZN\S*conv3x3_slide64_kernel\S*):.*?\n(.*?)\.end_amdhsa_kernel', asm, re.S | re.M):
+    for m in re.finditer(r'^(_ZN\S*' + kernel + r'\S*):.*?\n(.*?)\.end_amdhsa_kernel', asm, re.S | re.M):
         blocks, cur = [], []
         for l in m.group(2).split('\n'):
             s = l.strip()
@@ -51,7 +52,9 @@ def band_loops(asm):
             elif s and not s.startswith(';') and not s.startswith('.'):
                 cur.append(s.split(';')[0].strip())
         blocks.append(cur)
-        out.append((m.group(1), max(blocks, key=lambda b: sum('v_mfma' in x for x in b))))
+        for b in blocks:
+            if sum('v_mfma' in x for x in b) >= 100:
+                out.append((m.group(1), b))
     return out
 
 
@@ -95,32 +98,34 @@ def check(name, loop):
 
 
 def main():
-    src = ROOT / 'tedm_amd' / 'csrc' / 'conv_slide.hip'
-    with tempfile.TemporaryDirectory() as td:
-        out = Path(td) / 'conv_slide.s'
-        cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-gpu-rdc', '--cuda-device-only', '-S',
-               str(src), '-o', str(out)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr)
-            return 2
-        asm = out.read_text()
     rc = 0
-    loops = band_loops(asm)
-    if not loops:
-        print('no conv3x3_slide64_kernel instance found')
-        return 2
-    for name, loop in loops:
-        loads, bad, mix = check(name, loop)
-        nm = mix['mfma']
-        print(f'{name}: band loop {len(loop)} instructions, {nm} MFMA, per MFMA gap: ' +
-              ', '.join(f'{k} {v / max(nm, 1):.2f}' for k, v in sorted(mix.items()) if k != 'mfma') + f'; {len(loads)} loop-carried loads')
-        if nm != 216 or len(loads) != 18:
-            print('  UNEXPECTED band structure (216 MFMAs and 18 loads in one block expected)')
-            rc = 1
-        for i, l, vm in bad:
-            print(f'  NOT COVERED: {l} (instruction {i}): first use reached with {vm} vector-memory instructions in between and no vmcnt wait <= that')
-            rc = 1
+    # (source, kernel, expected (MFMAs, loop-carried loads) per band loop)
+    for fname, kernel, expect in (('conv_slide.hip', 'conv3x3_slide64_kernel', {(216, 18)}), ('conv_slide128.hip', 'conv3x3_slide128_kernel', {(108, 12), (108, 6)})):
+        src = ROOT / 'tedm_amd' / 'csrc' / fname
+        with tempfile.TemporaryDirectory() as td:
+            out = Path(td) / 'k.s'
+            cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-gpu-rdc', '--cuda-device-only', '-S',
+                   str(src), '-o', str(out)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                print(r.stderr)
+                return 2
+            asm = out.read_text()
+        loops = band_loops(asm, kernel)
+        if not loops:
+            print(f'no {kernel} band loop found')
+            return 2
+        for name, loop in loops:
+            loads, bad, mix = check(name, loop)
+            nm = mix['mfma']
+            print(f'{name}: band loop {len(loop)} instructions, {nm} MFMA, per MFMA gap: ' +
+                  ', '.join(f'{k} {v / max(nm, 1):.2f}' for k, v in sorted(mix.items()) if k != 'mfma') + f'; {len(loads)} loop-carried loads')
+            if (nm, len(loads)) not in expect:
+                print(f'  UNEXPECTED band structure: (MFMAs, loads) = {(nm, len(loads))}, expected one of {sorted(expect)}')
+                rc = 1
+            for i, l, vm in bad:
+                print(f'  NOT COVERED: {l} (instruction {i}): first use reached with {vm} vector-memory instructions in between and no vmcnt wait <= that')
+                rc = 1
     print('ok' if rc == 0 else 'FAILED')
     return rc
 
