@@ -2,6 +2,7 @@
 # Regenerate the measurement set under profiles/ on a GPU box (one MI355X):  bash tools/refresh_profiles.sh r02a
 # Writes scratch under gpurun_out/ and copies the judged summaries to profiles/<tag>_*.
 set -e
+set -x          # progress on stderr: a GPU box kills a command that stays silent for 7 minutes
 tag=${1:?usage: refresh_profiles.sh <tag>}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -26,8 +27,10 @@ python tools/conv_shape_profile.py > profiles/${tag}_conv_shape_profile.txt 2>/d
 # per-dispatch timeline of one forward step (every kernel in launch order)
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/trace_one_step.py gpurun_out/${tag}_trace > profiles/${tag}_step_timeline.txt
-# eps error over seeds / timesteps against the CPU oracle (test infrastructure)
-python tests/eps_margin.py 4 2>/dev/null > profiles/${tag}_eps_margin.txt
+# sliding-window conv kernels: lab timings with phase stamps (tools/build/slide_lab: hipcc ... -DSL_LAB_EXTRA tools/slide_lab.hip) and SQ counters
+if [ -x tools/build/slide_lab ]; then tools/build/slide_lab 10 3 > profiles/${tag}_slide_lab.txt 2>&1; fi
+if [ -x tools/build/slide_lab_plain ]; then bash tools/pmc_slide.sh > profiles/${tag}_pmc_sq_slide.txt 2>&1; fi
+# (the eps margin scan against the CPU oracle takes ~10 minutes of host time: python tests/eps_margin.py 4 > profiles/${tag}_eps_margin.txt)
 # gpurun merges only gpurun_out/ back: leave a copy there (copy it into profiles/ after the call)
 mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* gpurun_out/profiles_${tag}/
 echo "profiles/${tag}_* written (copy under gpurun_out/profiles_${tag}/)"
