@@ -73,12 +73,12 @@ int op_full_attention_backward(const float* qkv, const float* inv, const float* 
 size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo);
 int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho,
                   int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
-                  float* dw, int accumulate, hipStream_t st);
+                  float* dw, int accumulate, int fast /*1: single fp16 product on the 3x3 path (f16f4 training mode)*/, hipStream_t st);
 
 // wgrad_mfma.hip (bf16x3 matrix-core path for stride-1 3x3 / 1x1; called by op_conv_wgrad)
 size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo);
 int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
-                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, hipStream_t st);
+                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, hipStream_t st);
 int wgrad_set_tuning(const char* key, int v);
 int la_set_tuning(const char* key, int v);
 int wgrad_mfma_set_tuning(const char* key, int v);

@@ -205,8 +205,12 @@ static void wgrad_geometry(int k, int stride, int Cout, int Cin, int B, int Ho, 
 // tedm_set_tuning("wgrad_mfma", v): 0 = exact-fp32 MFMA kernel everywhere, 1 = bf16x3 matrix-core path for 3x3 (default;
 // 1x1 weight gradients are staging-bound and measured cheaper without the planar pre-pass)
 static int g_wgrad_mfma = 1;
+// tedm_set_tuning("wgrad_fp16", v): 1 (default) = callers that ask for the fast arithmetic (the f16f4 training mode) get ONE fp16 product
+// with a per-tensor power-of-two scale on the 3x3 weight gradients (wgrad_mfma.hip); 0 = bf16x3 for them too
+static int g_wgrad_fp16 = 1;
 int wgrad_set_tuning(const char* key, int v) {
     if (!strcmp(key, "wgrad_mfma") && (v == 0 || v == 1)) { g_wgrad_mfma = v; return TEDM_OK; }
+    if (!strcmp(key, "wgrad_fp16") && (v == 0 || v == 1)) { g_wgrad_fp16 = v; return TEDM_OK; }
     return wgrad_mfma_set_tuning(key, v);
 }
 
@@ -224,7 +228,7 @@ size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho,
 // dw (OIHW, Cout x (C1+C2) x k x k) = [accumulate ? dw : 0] + wgrad.  ups: 1 = the conv saw the nearest-x2 upsampled input.
 int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho,
                   int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
-                  float* dw, int accumulate, hipStream_t st) {
+                  float* dw, int accumulate, int fast, hipStream_t st) {
     const int Cin = C1 + C2;
     if (Cin % 4 || C1 % 4 || Cout % 4) return TEDM_EINVAL;
     WgradArgs a{};
@@ -232,7 +236,7 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     a.pro_a = pro_a; a.pro_b = pro_b; a.part = part;
     if (stride == 1 && k == 3 && g_wgrad_mfma && (pro == PRO_NONE || pro == PRO_GN)) {
         int S = 0;
-        const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, st);
+        const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, fast && g_wgrad_fp16, st);
         if (rc != TEDM_OK) return rc;
         const long long per = (long long)k * k * Cout * Cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(1024), 0, st, part, S, k * k, Cout, Cin, dw,

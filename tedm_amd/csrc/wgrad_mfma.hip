@@ -17,6 +17,14 @@
 //      before the MFMAs of tile t and written to LDS after them.  One partial per (split, column group); wgrad.hip's
 //      reduce kernel sums them in fixed order (deterministic, no atomics).
 // LDS channel strides are odd multiples of 16 B => the ds_read_b128 operand fetches are conflict-free.
+//
+// F16 instances (the f16f4 training mode): ONE fp16 product instead of three bf16 ones.  The reduction runs over ~10^5..10^6 pixels
+// whose operand roundings are independent, so an 11-bit significand costs ~4e-4 relative on a gradient tensor (inside that mode's
+// 3e-3 bound) -- but dY has no fixed range (1e-7 and smaller right behind an L1 loss with mean reduction), so it is scaled by a
+// power of two taken from its own absolute maximum (absmax_kernel: an integer atomic maximum of the bit patterns, order independent
+// and hence deterministic; the maximum lands in [2^12, 2^13)) and the partial sums are scaled back exactly.  X is the forward
+// pass's conv input, for which the f16f4 mode already requires |x| < 65504; the conversion saturates.  Half the plane bytes, a third
+// of the MFMAs; the plane loads then run TWO tiles ahead (two register sets) to keep as many bytes in flight.
 #include <string.h>
 
 #include "common.h"
@@ -24,6 +32,8 @@
 #include "../../include/tedm_hip.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP)
 
@@ -37,19 +47,43 @@ struct PlanarArgs {
     const float* pro_a; const float* pro_b;
     uint16_t* hi; uint16_t* lo;
     int Hp, tiles_x, ncb;    // plane rows, column tiles, channel blocks of 64
+    const unsigned* amax;    // F16: bit pattern of max |value| of the tensor (null: scale 1)
 };
+
+// power-of-two scale that puts a tensor's absolute maximum (bit pattern `u`) into [2^12, 2^13); 1 for an all-zero tensor
+TEDM_DEVFN float f16_plane_scale(unsigned u, bool inverse) {
+    if (u == 0u) return 1.f;
+    int e = (int)(u >> 23) - 127;                       // floor(log2 max)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const int k = inverse ? e - 12 : 12 - e;
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+
+// max |x| over n4 float4s as a bit pattern (non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, long long n4, unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = x[i];
+        m = max(max(m, __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu), __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu);
+        m = max(max(m, __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu), __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 
 TEDM_DEVFN uint32_t bf16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v); }
 
 // grid: (tiles_x, Hp, B*ncb).  One block = one plane row of one column tile x 64 channels (PW pixels each).
 // HALO 1: X planes (40 pixels from ox0-1), 0: dY planes (32 pixels from ox0).
-template <int PRO, int HALO>
+template <int PRO, int HALO, bool F16 = false>
 __global__ __launch_bounds__(256) void planar_split_kernel(PlanarArgs a) {
     constexpr int PW = HALO ? 40 : 32, NPAIR = PW / 2, RS = NPAIR + 1;      // RS odd: conflict-light transposed access
     constexpr int NCHUNK = PW / 8;
-    __shared__ uint32_t th[64 * RS], tl[64 * RS];
+    __shared__ uint32_t th[64 * RS], tl[F16 ? 1 : 64 * RS];
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2;
+    const float fs = (F16 && a.amax) ? f16_plane_scale(*a.amax, false) : 1.f;
     const int n = blockIdx.z / a.ncb, cb = blockIdx.z - n * a.ncb;
     const int yy = blockIdx.y, y = yy - 1, tx = blockIdx.x;
     const int c4 = (tid & 15) * 4, pp = tid >> 4;
@@ -84,11 +118,16 @@ __global__ __launch_bounds__(256) void planar_split_kernel(PlanarArgs a) {
             const float e0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, e1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const __bf16 h0 = (__bf16)e0[k], h1 = (__bf16)e1[k];
-                const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-                const uint32_t lb = bf16_bits(e0[k] - (float)h0) | (bf16_bits(e1[k] - (float)h1) << 16);
-                th[(c4 + k) * RS + pair] = hb;
-                tl[(c4 + k) * RS + pair] = lb;
+                if constexpr (F16) {
+                    const _Float16 h0 = (_Float16)fminf(fmaxf(e0[k] * fs, -65504.f), 65504.f), h1 = (_Float16)fminf(fmaxf(e1[k] * fs, -65504.f), 65504.f);
+                    th[(c4 + k) * RS + pair] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                } else {
+                    const __bf16 h0 = (__bf16)e0[k], h1 = (__bf16)e1[k];
+                    const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                    const uint32_t lb = bf16_bits(e0[k] - (float)h0) | (bf16_bits(e1[k] - (float)h1) << 16);
+                    th[(c4 + k) * RS + pair] = hb;
+                    tl[(c4 + k) * RS + pair] = lb;
+                }
             }
         }
     }
@@ -99,9 +138,11 @@ __global__ __launch_bounds__(256) void planar_split_kernel(PlanarArgs a) {
         const int c = i / NCHUNK, chunk = i - c * NCHUNK;
         if (cb * 64 + c < C) {
             const uint32_t* ph = th + c * RS + chunk * 4;
-            const uint32_t* pl = tl + c * RS + chunk * 4;
             *(uint4*)(a.hi + base + (size_t)i * 8) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-            *(uint4*)(a.lo + base + (size_t)i * 8) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            if constexpr (!F16) {
+                const uint32_t* pl = tl + c * RS + chunk * 4;
+                *(uint4*)(a.lo + base + (size_t)i * 8) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            }
         }
     }
 }
@@ -264,6 +305,121 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_kernel(WgArgs a) {
     }
 }
 
+// The single-fp16-product instance: same geometry, only the "hi" planes exist (dY scaled, see the header), 18 MFMAs per tile
+// instead of 54 and half the bytes -- so the plane loads run TWO tiles ahead (register sets R0 / R1, the loop body is a pair of
+// tiles) to keep the bytes in flight the bf16x3 kernel has with one.  Partials are scaled back by the exact inverse scale.
+__global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const unsigned* __restrict__ amax) {
+    constexpr int HR = TR + 2, XCH = 5, XS = 336, DS = 144;
+    constexpr int NX = 64 * HR * XCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sdy = smem;
+    char* sx = sdy + 64 * DS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int cg = wave >> 2, wc = (wave >> 1) & 1, wi = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = xcd + 8 * (slot / a.nblk), blk = slot % a.nblk;
+    if (split >= a.S) return;                         // whole workgroup leaves before any barrier
+    const int cob = blk / a.nci_blk, cib = blk - cob * a.nci_blk;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int tpi = a.tiles_x * a.tiles_y, ntile = a.B * tpi;
+    const int t_beg = split * a.tpw, t_end = (t_beg + a.tpw < ntile) ? t_beg + a.tpw : ntile;
+    const unsigned dy_row = (unsigned)a.tiles_x * a.Cout * 32, x_row = (unsigned)a.tiles_x * a.Cin * 40;
+
+    unsigned g_dy0, g_x[3];
+    int l_dy0, l_x[3];
+    uint32_t m_dy0, m_x[3];
+    {
+        const int row = tid >> 8, rem = tid & 255, c = rem >> 2, q = rem & 3;
+        const int ch = co0 + c;
+        m_dy0 = ch < a.Cout ? ~0u : 0u;
+        g_dy0 = (unsigned)(1 + row) * dy_row + (unsigned)(ch < a.Cout ? ch : a.Cout - 1) * 32 + q * 8;
+        l_dy0 = c * DS + row * 64 + q * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = tid + 512 * j, ic = i < NX ? i : NX - 1;
+        const int row = ic / 320, rem = ic - row * 320, c = rem / 5, q = rem - c * 5;
+        const int ch = ci0 + c;
+        m_x[j] = ch < a.Cin ? ~0u : 0u;
+        g_x[j] = (unsigned)row * x_row + (unsigned)(ch < a.Cin ? ch : a.Cin - 1) * 40 + q * 8;
+        l_x[j] = c * XS + row * (XCH * 16) + q * 16;
+    }
+    struct Regs { uint4 d, x0, x1, x2; };
+    auto issue = [&](int tl, Regs& R) __attribute__((always_inline)) {
+        const int tc = tl < t_end ? tl : t_end - 1;                      // past the end: an unused re-load (branch-free loop)
+        const int n_ = tc / tpi, trem_ = tc - n_ * tpi;
+        const int tx_ = trem_ / a.tiles_y, ty_ = trem_ - tx_ * a.tiles_y;
+        const size_t rowb = (size_t)(n_ * a.Hp + ty_ * TR) * a.tiles_x + tx_;
+        const uint16_t *bdy = a.dyh + rowb * a.Cout * 32, *bx = a.xh + rowb * a.Cin * 40;
+        R.d = *(const uint4*)(bdy + g_dy0);
+        R.x0 = *(const uint4*)(bx + g_x[0]); R.x1 = *(const uint4*)(bx + g_x[1]); R.x2 = *(const uint4*)(bx + g_x[2]);
+    };
+    auto put = [&](char* base, int off, const uint4& v, uint32_t m) __attribute__((always_inline)) {
+        u32x4 w = {v.x & m, v.y & m, v.z & m, v.w & m};
+        *(u32x4*)(base + off) = w;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const char* pdy = sdy + (wc * 32 + r) * DS + h * 16 + cg * 32;
+    const char* px = sx + (wi * 32 + r) * XS + h * 16 + cg * 32;
+
+    auto tile = [&](int tl, Regs& R) __attribute__((always_inline)) {
+        __syncthreads();                               // every wave is done reading the previous tile
+        put(sdy, l_dy0, R.d, m_dy0);
+        put(sx, l_x[0], R.x0, m_x[0]); put(sx, l_x[1], R.x1, m_x[1]); put(sx, l_x[2], R.x2, m_x[2]);
+        __syncthreads();
+        issue(tl + 2, R);                              // in flight during this tile's and the next tile's MFMAs
+        f16x8 av[TR];
+#pragma unroll
+        for (int row = 0; row < TR; ++row) av[row] = __builtin_bit_cast(f16x8, *(const u32x4*)(pdy + row * 64));
+#pragma unroll
+        for (int hy = 0; hy < HR; ++hy) {
+            const u32x4 q = *(const u32x4*)(px + hy * (XCH * 16));
+            const uint32_t nx = *(const uint32_t*)(px + hy * (XCH * 16) + 16);
+            f16x8 bv[3];
+            bv[0] = __builtin_bit_cast(f16x8, q);
+            const u32x4 s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                              __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(nx, q[3], 16)};
+            const u32x4 s2 = {q[1], q[2], q[3], nx};
+            bv[1] = __builtin_bit_cast(f16x8, s1);
+            bv[2] = __builtin_bit_cast(f16x8, s2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int row = hy - ky;
+                if (row < 0 || row >= TR) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[row], bv[kx], acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+    };
+    Regs R0, R1;
+    issue(t_beg, R0);
+    issue(t_beg + 1, R1);
+    int tl = t_beg;
+    for (; tl + 1 < t_end; tl += 2) { tile(tl, R0); tile(tl + 1, R1); }
+    if (tl < t_end) tile(tl, R0);
+
+    const float inv = amax ? f16_plane_scale(*amax, true) : 1.f;
+    const int ci = ci0 + wi * 32 + r;
+    const size_t sp = (size_t)split * 2 + cg;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = co0 + wc * 32 + acc_row(i, h);
+            if (co < a.Cout && ci < a.Cin)
+                a.part[((sp * 9 + t) * a.Cout + co) * a.Cin + ci] = acc[t][i] * inv;
+        }
+    }
+}
+
 struct Geo { int tiles_x, tiles_y, Hp, S, tpw, nco, nci; };
 Geo geometry(int Cout, int Cin, int B, int Ho, int Wo) {
     Geo g;
@@ -284,11 +440,20 @@ Geo geometry(int Cout, int Cin, int B, int Ho, int Wo) {
 size_t plane_elems(const Geo& g, int B, int C, int pw) { return (size_t)B * g.Hp * g.tiles_x * C * pw; }
 
 int launch_planar(const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Hout, int Wout, int ups, int halo, int pro,
-                  const float* pa, const float* pb, uint16_t* hi, uint16_t* lo, const Geo& g, hipStream_t st) {
+                  const float* pa, const float* pb, uint16_t* hi, uint16_t* lo, const Geo& g, hipStream_t st, bool f16 = false,
+                  const unsigned* amax = nullptr) {
     PlanarArgs a{};
+    a.amax = amax;
     a.x1 = x1; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.B = B; a.H = H; a.W = W; a.Hout = Hout; a.Wout = Wout; a.ups = ups;
     a.pro_a = pa; a.pro_b = pb; a.hi = hi; a.lo = lo; a.Hp = g.Hp; a.tiles_x = g.tiles_x; a.ncb = (C1 + C2 + 63) / 64;
     dim3 grid(g.tiles_x, g.Hp, B * a.ncb);
+    if (f16) {
+        if (!halo && pro == PRO_NONE) hipLaunchKernelGGL((planar_split_kernel<PRO_NONE, 0, true>), grid, dim3(256), 0, st, a);
+        else if (halo && pro == PRO_NONE) hipLaunchKernelGGL((planar_split_kernel<PRO_NONE, 1, true>), grid, dim3(256), 0, st, a);
+        else if (halo && pro == PRO_GN) hipLaunchKernelGGL((planar_split_kernel<PRO_GN, 1, true>), grid, dim3(256), 0, st, a);
+        else return TEDM_EINVAL;
+        return LAUNCH_OK();
+    }
     if (!halo && pro == PRO_NONE) hipLaunchKernelGGL((planar_split_kernel<PRO_NONE, 0>), grid, dim3(256), 0, st, a);
     else if (halo && pro == PRO_NONE) hipLaunchKernelGGL((planar_split_kernel<PRO_NONE, 1>), grid, dim3(256), 0, st, a);
     else if (halo && pro == PRO_GN) hipLaunchKernelGGL((planar_split_kernel<PRO_GN, 1>), grid, dim3(256), 0, st, a);
@@ -312,7 +477,7 @@ size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo) {
 // 3x3, stride 1, prologue NONE or GN.  ups: the conv read the nearest-x2 upsampled input (H,W are the SOURCE size, Ho=2H).
 // Fills part[S'][9][Cout][Cin] and returns S' in *S_out; the caller runs the split reduction.
 int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
-                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, hipStream_t st) {
+                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, hipStream_t st) {
     const int Cin = C1 + C2;
     if (k != 3 || Cin % 4 || C1 % 4 || Cout % 4 || (pro != PRO_NONE && pro != PRO_GN)) return TEDM_EINVAL;
     const Geo g = geometry(Cout, Cin, B, Ho, Wo);
@@ -323,6 +488,25 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
     uint16_t* dyl = dyh + ndy;
     uint16_t* xh = dyl + ndy;
     uint16_t* xl = xh + nx;
+    if (f16) {
+        // (the planes of the bf16x3 layout are reserved either way: dyl's first word holds the maximum, xh stays where it is)
+        unsigned* amax = (unsigned*)dyl;
+        if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return TEDM_EHIP;
+        const long long n4 = (long long)B * Ho * Wo * Cout / 4;
+        const int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
+        hipLaunchKernelGGL(absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, (const float4*)dy, n4, amax);
+        int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, nullptr, g, st, true, amax);
+        if (rc != TEDM_OK) return rc;
+        rc = launch_planar(x1, C1, x2, C2, B, H, W, Ho, Wo, ups, 1, pro, pro_a, pro_b, xh, nullptr, g, st, true, nullptr);
+        if (rc != TEDM_OK) return rc;
+        WgArgs a{};
+        a.dyh = dyh; a.xh = xh; a.Cout = Cout; a.Cin = Cin; a.B = B; a.Hp = g.Hp;
+        a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.part = ws; a.S = g.S; a.tpw = g.tpw; a.nci_blk = g.nci; a.nblk = g.nco * g.nci;
+        *S_out = 2 * g.S;
+        const size_t lds = (size_t)64 * (144 + 336);
+        hipLaunchKernelGGL(wgrad_mfma8_f16_kernel, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, (const unsigned*)amax);
+        return LAUNCH_OK();
+    }
     int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, dyl, g, st);
     if (rc != TEDM_OK) return rc;
     rc = launch_planar(x1, C1, x2, C2, B, H, W, Ho, Wo, ups, 1, pro, pro_a, pro_b, xh, xl, g, st);

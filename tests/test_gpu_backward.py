@@ -72,6 +72,41 @@ def test_conv_backward(lib, dev, case):
     assert rel(outs[0][1], w.grad) < TOL
 
 
+@pytest.mark.parametrize('dy_scale', [1.0, 3e-9, 7e6], ids=['dy~1', 'dy~3e-9', 'dy~7e6'])
+@pytest.mark.parametrize('case', [(64, 64, 24, 40, 2, 0), (96, 128, 17, 33, 2, 0), (128, 64, 12, 20, 2, 1)], ids=lambda c: '{}to{}_{}x{}_u{}'.format(c[0], c[1], c[2], c[3], c[5]))
+def test_conv3x3_weight_gradient_single_fp16_product(lib, dev, case, dy_scale):
+    """The f16f4 training mode's 3x3 weight gradients (wgrad_mfma.hip, F16 instances): ONE fp16 product over operands rounded to 11
+    bits, dY scaled by a power of two taken from its own maximum.  Against fp64 autograd: the roundings are independent over the
+    ~10^3..10^4 pixels of these cases, so the tensor error stays at a few 1e-4 -- for ANY magnitude of dY (an unscaled fp16 dY would be
+    all zeros at 3e-9 and all infinities at 7e6) -- and the result is deterministic (the maximum is an integer atomic max)."""
+    from tedm_amd import _lib
+    Cin, Cout, H, W, B, ups = case
+    x = rnd(B, Cin, H, W, seed=1).double()
+    w = (rnd(Cout, Cin, 3, 3, seed=2) / (Cin * 9) ** 0.5).double().requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    y = F.conv2d(xin, w, None, padding=1)
+    dy = rnd(*y.shape, seed=3).double() * dy_scale
+    y.backward(dy)
+    d = lambda t: t.float().contiguous().to(dev)
+    DY, X, Wt = d(nhwc(dy)), d(nhwc(x)), d(w.detach())
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=dev)
+        _lib.check(lib.tedm_op_conv2d_backward(DY.data_ptr(), X.data_ptr(), Wt.data_ptr(), B, H, W, Cin, Cout, 3, 1, ups,
+                                               None, dw.data_ptr(), 3, torch.cuda.current_stream(dev).cuda_stream), 'tedm_op_conv2d_backward')
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    e = rel(outs[0], w.grad)
+    print(f'single-fp16 wgrad {case} dy x {dy_scale:g}: rel-L2 {e:.2e}')
+    assert 1e-6 < e < 1e-3            # (above 1e-6: it IS the 11-bit path, not the bf16x3 one)
+    # all-zero dY: scale 1, exact zeros
+    dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=dev)
+    Z = torch.zeros_like(DY)
+    _lib.check(lib.tedm_op_conv2d_backward(Z.data_ptr(), X.data_ptr(), Wt.data_ptr(), B, H, W, Cin, Cout, 3, 1, ups,
+                                           None, dw.data_ptr(), 3, torch.cuda.current_stream(dev).cuda_stream), 'tedm_op_conv2d_backward')
+    assert float(dw.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('B,H,W,Cc,film', [(2, 24, 40, 64, True), (3, 17, 9, 128, False), (2, 32, 64, 512, True)])
 def test_gn_film_silu_backward(lib, dev, B, H, W, Cc, film):
     """Block tail (GroupNorm(8) -> x*(scale+1)+shift -> SiLU, unet_model.py:126-135) backward vs autograd."""
