@@ -296,11 +296,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ fa, const float* __restrict__ fb,
                                                            const float* __restrict__ mr, const float* __restrict__ ca,
                                                            const float* __restrict__ mcoef, int groups, long long hw, int C,
-                                                           int lpp, long long P, float* __restrict__ dy) {
+                                                           int lpp, long long P, float* __restrict__ dy,
+                                                           unsigned* __restrict__ amax /*nullable: max |dy| as a bit pattern*/) {
     const int lane = threadIdx.x & 63, q = lane & (lpp - 1), sub = lane / lpp, ppw = 64 / lpp;
     const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const int cg = C / groups;
+    unsigned am = 0u;
     for (long long p0 = wave_id * ppw; p0 < P; p0 += nwaves * ppw) {
         const long long p = p0 + sub;
         if (p >= P) continue;
@@ -322,7 +324,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             GN_APP(x, 0) GN_APP(y, 1) GN_APP(z, 2) GN_APP(w, 3)
 #undef GN_APP
             *(float4*)(dy + o) = r;
+            am = max(max(am, __builtin_bit_cast(unsigned, r.x) & 0x7fffffffu), __builtin_bit_cast(unsigned, r.y) & 0x7fffffffu);
+            am = max(max(am, __builtin_bit_cast(unsigned, r.z) & 0x7fffffffu), __builtin_bit_cast(unsigned, r.w) & 0x7fffffffu);
         }
+    }
+    if (amax) {      // (an integer maximum: order independent, the result is deterministic; consumed by the fp16 weight gradient)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o));
+        if (lane == 0 && am) atomicMax(amax, am);
     }
 }
 
@@ -764,9 +773,10 @@ int gn_bwd_chunks(long long hw) {
 int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
                         const float* beta, const float* film, int film_stride, float* dfilm, int B, long long hw, int C,
                         int groups, float* slab, float* ca, float* mcoef, float* dgam_n, float* dbet_n, float* dbias_n,
-                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st) {
+                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, unsigned* amax, hipStream_t st) {
     PixMap m;
     if (!pixmap(C, m) || C % groups) return TEDM_EINVAL;
+    if (amax && hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return TEDM_EHIP;
     const int E = gn_bwd_chunks(hw);
     const int ppb = (int)((hw + E - 1) / E);
     DISPATCH_V(m.v, gn_bwd_reduce_kernel, dim3(E, B), dim3(256), 0, st, G, y, fa, fb, mr, groups, hw, C, m.lpp, ppb, slab);
@@ -779,7 +789,7 @@ int op_gn_silu_backward(const float* G, const float* y, const float* fa, const f
     long long waves = (P + (64 / m.lpp) - 1) / (64 / m.lpp), blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     DISPATCH_V(m.v, gn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, y, fa, fb, mr, ca, mcoef, groups, hw, C,
-               m.lpp, P, dy);
+               m.lpp, P, dy, amax);
     return LAUNCH_OK();
 }
 

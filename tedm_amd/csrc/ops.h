@@ -73,12 +73,13 @@ int op_full_attention_backward(const float* qkv, const float* inv, const float* 
 size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho, int Wo);
 int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho,
                   int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
-                  float* dw, int accumulate, int fast /*1: single fp16 product on the 3x3 path (f16f4 training mode)*/, hipStream_t st);
+                  float* dw, int accumulate, int fast /*1: single fp16 product on the 3x3 path (f16f4 training mode)*/,
+                  const unsigned* dy_amax /*nullable: max |dy| bits if the producer of dy already has it*/, hipStream_t st);
 
 // wgrad_mfma.hip (bf16x3 matrix-core path for stride-1 3x3 / 1x1; called by op_conv_wgrad)
 size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo);
 int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
-                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, hipStream_t st);
+                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, const unsigned* dy_amax, hipStream_t st);
 int wgrad_set_tuning(const char* key, int v);
 int la_set_tuning(const char* key, int v);
 int wgrad_mfma_set_tuning(const char* key, int v);
@@ -108,7 +109,7 @@ int gn_bwd_chunks(long long hw);
 int op_gn_silu_backward(const float* G, const float* y, const float* fa, const float* fb, const float* mr, const float* gamma,
                         const float* beta, const float* film, int film_stride, float* dfilm, int B, long long hw, int C,
                         int groups, float* slab, float* ca, float* mcoef, float* dgam_n, float* dbet_n, float* dbias_n,
-                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st);
+                        float* dy, float* dgamma, float* dbeta, float* dbias, int accumulate, unsigned* amax /*nullable: out, max |dy| bits*/, hipStream_t st);
 int ln_bwd_blocks(long long P, int C);
 int op_ln_backward(const float* dY, const float* x, const float* g, const float* add, float* dx, float* part, float* dg,
                    int accumulate, long long P, int C, hipStream_t st);

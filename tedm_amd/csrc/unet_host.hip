@@ -1078,7 +1078,7 @@ int tedm_conv1x1_wgrad_nhwc(const float* dy, const float* x, int B, int H, int W
     if (!dy || !x || !dw || !workspace) return fail(TEDM_EINVAL, "null argument");
     if (workspace_bytes < tedm_conv1x1_wgrad_workspace_bytes(Cout, Cin, B, H, W)) return fail(TEDM_ENOMEM, "wgrad workspace too small");
     float* part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    const int rc = op_conv_wgrad(dy, Cout, x, Cin, nullptr, 0, B, H, W, H, W, 1, 1, 0, PRO_NONE, nullptr, nullptr, part, dw, accumulate, 0,
+    const int rc = op_conv_wgrad(dy, Cout, x, Cin, nullptr, 0, B, H, W, H, W, 1, 1, 0, PRO_NONE, nullptr, nullptr, part, dw, accumulate, 0, nullptr,
                                  (hipStream_t)stream);
     return rc == TEDM_OK ? rc : fail(rc, "conv1x1 wgrad failed (%d)", rc);
 }
@@ -1382,7 +1382,7 @@ int tedm_op_conv2d_backward(const float* dy, const float* x, const float* weight
         const size_t pf = wgrad_partial_floats(k, stride, Cout, Cin, B, Ho, Wo);
         if (rc == TEDM_OK && hipMalloc((void**)&part, pf * 4) != hipSuccess) rc = TEDM_ENOMEM;
         if (rc == TEDM_OK) rc = op_conv_wgrad(dy, Cout, x, Cin, nullptr, 0, B, H, W, Ho, Wo, k, stride, upsample, PRO_NONE,
-                                              nullptr, nullptr, part, dw, 0, prec == TEDM_PREC_F16F4, st);
+                                              nullptr, nullptr, part, dw, 0, prec == TEDM_PREC_F16F4, nullptr, st);
     }
     (void)hipStreamSynchronize(st);
     if (wpk) (void)hipFree(wpk);
@@ -1407,7 +1407,7 @@ int tedm_op_gn_silu_backward(const float* G, const float* y, const float* fa, co
     float* slab = ws; float* ca = slab + (size_t)B * E * Cc * 3; float* dg = ca + (size_t)B * Cc; float* db = dg + (size_t)B * Cc;
     float* dbi = db + (size_t)B * Cc; float* mc = dbi + (size_t)B * Cc;
     const int rc = op_gn_silu_backward(G, y, fa, fb, mr, gamma, beta, film, film_stride, dfilm, B, hw, Cc, groups, slab, ca, mc,
-                                       dg, db, dbi, dy, dgamma, dbeta, dbias, 0, st);
+                                       dg, db, dbi, dy, dgamma, dbeta, dbias, 0, nullptr, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(ws);
     return rc == TEDM_OK ? rc : fail(rc, "tedm_op_gn_silu_backward failed (%d)", rc);

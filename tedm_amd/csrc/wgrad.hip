@@ -228,7 +228,7 @@ size_t wgrad_partial_floats(int k, int stride, int Cout, int Cin, int B, int Ho,
 // dw (OIHW, Cout x (C1+C2) x k x k) = [accumulate ? dw : 0] + wgrad.  ups: 1 = the conv saw the nearest-x2 upsampled input.
 int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho,
                   int Wo, int k, int stride, int ups, int pro, const float* pro_a, const float* pro_b, float* part,
-                  float* dw, int accumulate, int fast, hipStream_t st) {
+                  float* dw, int accumulate, int fast, const unsigned* dy_amax, hipStream_t st) {
     const int Cin = C1 + C2;
     if (Cin % 4 || C1 % 4 || Cout % 4) return TEDM_EINVAL;
     WgradArgs a{};
@@ -236,7 +236,7 @@ int op_conv_wgrad(const float* dy, int Cout, const float* x1, int C1, const floa
     a.pro_a = pro_a; a.pro_b = pro_b; a.part = part;
     if (stride == 1 && k == 3 && g_wgrad_mfma && (pro == PRO_NONE || pro == PRO_GN)) {
         int S = 0;
-        const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, fast && g_wgrad_fp16, st);
+        const int rc = op_conv_wgrad_mfma(dy, Cout, x1, C1, x2, C2, B, H, W, Ho, Wo, k, ups, pro, pro_a, pro_b, part, &S, fast && g_wgrad_fp16, dy_amax, st);
         if (rc != TEDM_OK) return rc;
         const long long per = (long long)k * k * Cout * Cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(1024), 0, st, part, S, k * k, Cout, Cin, dw,

@@ -420,6 +420,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
     }
 }
 
+int g_wgrad_splits = 512;     // tedm_set_tuning("wgrad_splits", n): pixel splits x channel blocks aimed at (n workgroups = n / 256 rounds of one per CU)
 struct Geo { int tiles_x, tiles_y, Hp, S, tpw, nco, nci; };
 Geo geometry(int Cout, int Cin, int B, int Ho, int Wo) {
     Geo g;
@@ -429,7 +430,7 @@ Geo geometry(int Cout, int Cin, int B, int Ho, int Wo) {
     g.nco = (Cout + 63) / 64;
     g.nci = (Cin + 63) / 64;
     const long long ntile = (long long)B * g.tiles_x * g.tiles_y;
-    long long s = 512 / ((long long)g.nco * g.nci);      // ~2 rounds of one resident workgroup per CU x 256 CUs
+    long long s = g_wgrad_splits / ((long long)g.nco * g.nci);      // default: ~2 rounds of one resident workgroup per CU x 256 CUs
     if (s > ntile) s = ntile;
     if (s < 1) s = 1;
     const long long t = (ntile + s - 1) / s;
@@ -463,7 +464,10 @@ int launch_planar(const float* x1, int C1, const float* x2, int C2, int B, int H
 
 }  // namespace
 
-int wgrad_mfma_set_tuning(const char*, int) { return TEDM_EINVAL; }
+int wgrad_mfma_set_tuning(const char* key, int v) {
+    if (!strcmp(key, "wgrad_splits") && v >= 64 && v <= 4096) { g_wgrad_splits = v; return TEDM_OK; }
+    return TEDM_EINVAL;
+}
 
 // Workspace (in floats) of the MFMA path: partials + four bf16 tile planes.
 size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo) {
@@ -477,7 +481,7 @@ size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo) {
 // 3x3, stride 1, prologue NONE or GN.  ups: the conv read the nearest-x2 upsampled input (H,W are the SOURCE size, Ho=2H).
 // Fills part[S'][9][Cout][Cin] and returns S' in *S_out; the caller runs the split reduction.
 int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const float* x2, int C2, int B, int H, int W, int Ho, int Wo,
-                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, hipStream_t st) {
+                       int k, int ups, int pro, const float* pro_a, const float* pro_b, float* ws, int* S_out, int f16, const unsigned* dy_amax, hipStream_t st) {
     const int Cin = C1 + C2;
     if (k != 3 || Cin % 4 || C1 % 4 || Cout % 4 || (pro != PRO_NONE && pro != PRO_GN)) return TEDM_EINVAL;
     const Geo g = geometry(Cout, Cin, B, Ho, Wo);
@@ -490,11 +494,15 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
     uint16_t* xl = xh + nx;
     if (f16) {
         // (the planes of the bf16x3 layout are reserved either way: dyl's first word holds the maximum, xh stays where it is)
-        unsigned* amax = (unsigned*)dyl;
-        if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return TEDM_EHIP;
-        const long long n4 = (long long)B * Ho * Wo * Cout / 4;
-        const int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
-        hipLaunchKernelGGL(absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, (const float4*)dy, n4, amax);
+        const unsigned* amax = dy_amax;
+        if (!amax) {                                   // the producer of dY did not track it: one more pass over dY
+            unsigned* am = (unsigned*)dyl;
+            if (hipMemsetAsync(am, 0, 4, st) != hipSuccess) return TEDM_EHIP;
+            const long long n4 = (long long)B * Ho * Wo * Cout / 4;
+            const int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
+            hipLaunchKernelGGL(absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, (const float4*)dy, n4, am);
+            amax = am;
+        }
         int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, nullptr, g, st, true, amax);
         if (rc != TEDM_OK) return rc;
         rc = launch_planar(x1, C1, x2, C2, B, H, W, Ho, Wo, ups, 1, pro, pro_a, pro_b, xh, nullptr, g, st, true, nullptr);
@@ -504,7 +512,7 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.part = ws; a.S = g.S; a.tpw = g.tpw; a.nci_blk = g.nci; a.nblk = g.nco * g.nci;
         *S_out = 2 * g.S;
         const size_t lds = (size_t)64 * (144 + 336);
-        hipLaunchKernelGGL(wgrad_mfma8_f16_kernel, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, (const unsigned*)amax);
+        hipLaunchKernelGGL(wgrad_mfma8_f16_kernel, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, amax);
         return LAUNCH_OK();
     }
     int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, dyl, g, st);
