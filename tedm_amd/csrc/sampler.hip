@@ -10,6 +10,10 @@
 // unsigned integers and a 4-pass radix select (8 + 8 + 8 + 7 bits, per-wave LDS histograms) finds the order statistic of rank
 // floor(q (n - 1)); its upper neighbour is the same value or the minimum of the larger elements (one more pass).  The
 // interpolation is torch.quantile's: ranks = q (n - 1) in fp32 (the host passes floor and weight), lerp as ATen/native/Lerp.h.
+// Samples of up to 64 K values (256 x 256, the size the model is used at) take the register-resident instance: every thread keeps
+// its 64 values, and the order statistic is built bit by bit -- 31 rounds of "how many values are below prefix | bit?", each one
+// compare + add per value, a wave reduction and ONE barrier (LDS histograms with atomics cost 165 us per step here: the values
+// of a pass crowd into a few bins and same-address LDS atomics serialise; this form takes ~20 us).
 #include "common.h"
 #include "ops.h"
 #include "../../include/tedm_hip.h"
@@ -106,6 +110,104 @@ __global__ __launch_bounds__(SP_T) void sampler_step_kernel(SamplerArgs a) {
     }
 }
 
+
+constexpr int SP_EPT = 64;                                    // values per thread of the register-resident instance
+
+__global__ __launch_bounds__(SP_T) void sampler_step_reg_kernel(SamplerArgs a) {
+    __shared__ unsigned sh_c[2][SP_W];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int n = (int)a.chw;
+    long long ti = a.t[b];
+    ti = ti < 0 ? 0 : (ti >= a.T ? a.T - 1 : ti);
+    const float c_r = a.sqrt_recip_acp[ti], c_m = a.sqrt_recipm1_acp[ti];
+    const float* xt = a.x_t + (size_t)b * n;
+    const float* mo = a.model_out + (size_t)b * n;
+    float* x0 = a.x0 + (size_t)b * n;
+
+    // |x0| bit patterns (0xffffffff past the end: never below a candidate, never the minimum), signs in a 64-bit mask
+    unsigned u[SP_EPT];
+    unsigned long long sg = 0ull;
+#pragma unroll
+    for (int i = 0; i < SP_EPT; ++i) {
+        const int e = tid + i * SP_T;
+        u[i] = 0xffffffffu;
+        if (e < n) {
+            const float v = a.objective == 0 ? c_r * xt[e] - c_m * mo[e] : mo[e];
+            const unsigned bits = __builtin_bit_cast(unsigned, v);
+            u[i] = bits & 0x7fffffffu;
+            sg |= (unsigned long long)(bits >> 31) << i;
+        }
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // eight values' loads in flight at a time (128-register budget)
+    }
+    int round = 0;
+    auto block_sum = [&](unsigned c) -> unsigned {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += (unsigned)__shfl_xor((int)c, o);
+        const int par = round++ & 1;                           // two buffers: one barrier per round
+        if (lane == 0) sh_c[par][wave] = c;
+        __syncthreads();
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < SP_W; ++w) t += sh_c[par][w];
+        return t;
+    };
+    float s = 1.f;
+    if (a.clip) {
+        // largest v with count(u < v) <= k: the value of rank k (0-based) in ascending order
+        unsigned v = 0u;
+        const unsigned k = (unsigned)a.k_lo;
+#pragma unroll 1
+        for (int bit = 30; bit >= 0; --bit) {
+            const unsigned cand = v | (1u << bit);
+            unsigned c = 0;
+#pragma unroll
+            for (int i = 0; i < SP_EPT; ++i) c += u[i] < cand ? 1u : 0u;
+            if (block_sum(c) <= k) v = cand;
+        }
+        const float v_lo = __builtin_bit_cast(float, v);
+        float v_hi = v_lo;
+        if (a.w != 0.f) {
+            unsigned c = 0, m = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < SP_EPT; ++i) { c += u[i] <= v ? 1u : 0u; m = (u[i] > v && u[i] < m) ? u[i] : m; }
+            const unsigned c_le = block_sum(c);
+            if (k + 1 >= c_le) {                               // rank k + 1 lies past the copies of v: the smallest larger value
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+                const int par = round++ & 1;
+                if (lane == 0) sh_c[par][wave] = m;
+                __syncthreads();
+                unsigned mm = 0xffffffffu;
+#pragma unroll
+                for (int w = 0; w < SP_W; ++w) mm = min(mm, sh_c[par][w]);
+                v_hi = mm == 0xffffffffu ? v_lo : __builtin_bit_cast(float, mm);
+            }
+        }
+        const float q = a.w < 0.5f ? v_lo + a.w * (v_hi - v_lo) : v_hi - (v_hi - v_lo) * (1.f - a.w);     // torch.lerp (ATen/native/Lerp.h)
+        s = fmaxf(q, 1.f);
+    }
+    if (tid == 0 && a.s_out) a.s_out[b] = s;
+
+    const float k1 = a.coef1[ti], k2 = a.coef2[ti];
+    const float sig = (a.noise && ti > 0) ? expf(0.5f * a.logvar[ti]) : 0.f;
+    const float* nz = a.noise ? a.noise + (size_t)b * n : nullptr;
+    float* mean = a.mean ? a.mean + (size_t)b * n : nullptr;
+    float* xp = a.x_prev ? a.x_prev + (size_t)b * n : nullptr;
+#pragma unroll
+    for (int i = 0; i < SP_EPT; ++i) {
+        const int e = tid + i * SP_T;
+        if (e < n) {
+            float v = __builtin_bit_cast(float, u[i] | ((unsigned)((sg >> i) & 1ull) << 31));
+            if (a.clip) v = fminf(fmaxf(v, -s), s) / s;
+            x0[e] = v;
+            const float m = k1 * v + k2 * xt[e];
+            if (mean) mean[e] = m;
+            if (xp) xp[e] = nz ? m + sig * nz[e] : m;
+        }
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 }  // namespace
 
 extern "C" int tedm_sampler_step(const float* x_t, const float* model_out, const int64_t* t, const float* noise, const float* sqrt_recip_acp,
@@ -117,6 +219,7 @@ extern "C" int tedm_sampler_step(const float* x_t, const float* model_out, const
         return TEDM_EINVAL;
     SamplerArgs a{x_t, model_out, (const long long*)t, noise, sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, logvar,
                   x0, mean, x_prev, s_out, chw, T, objective, clip, (int)k_lo, w};
-    hipLaunchKernelGGL(sampler_step_kernel, dim3(B), dim3(SP_T), 0, (hipStream_t)stream, a);
+    if (chw <= (long long)SP_EPT * SP_T) hipLaunchKernelGGL(sampler_step_reg_kernel, dim3(B), dim3(SP_T), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(sampler_step_kernel, dim3(B), dim3(SP_T), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? TEDM_OK : TEDM_EHIP;
 }
