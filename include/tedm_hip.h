@@ -248,6 +248,9 @@ int tedm_pool_sum_nhwc(const float* g, int B, int h, int w, int factor, int C, f
 
 const char* tedm_last_error(void);
 const char* tedm_version(void);
+/* sha256 (hex) of the sources this binary was compiled from (tedm_amd/build.py: every file under tedm_amd/csrc and include/);
+ * the Python loader refuses a library whose digest differs from the tree it sits in. */
+const char* tedm_source_digest(void);
 
 #ifdef __cplusplus
 }

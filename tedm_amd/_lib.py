@@ -35,6 +35,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     'tedm_last_error': (C.c_char_p, []),
     'tedm_version': (C.c_char_p, []),
+    'tedm_source_digest': (C.c_char_p, []),
     'tedm_unet_create': (C.c_int, [C.POINTER(UnetCfg), C.POINTER(_P)]),
     'tedm_unet_destroy': (None, [_P]),
     'tedm_unet_num_params': (C.c_int, [_P]),
@@ -123,6 +124,18 @@ def lib() -> C.CDLL:
                 f'{path} not found: build it with `python -m tedm_amd.build` (hipcc, gfx950). '
                 'tedm_amd has no CPU/PyTorch fallback for the UNet hot path.')
         handle = C.CDLL(str(path))
+        if 'TEDM_HIP_LIB' not in os.environ and os.environ.get('TEDM_ALLOW_STALE_LIB') != '1':
+            # the binary must be the one built from the sources next to it (tedm_amd/build.py: digest of csrc/ + include/)
+            from . import build as _build
+            try:
+                handle.tedm_source_digest.restype = C.c_char_p
+                have = handle.tedm_source_digest().decode()
+            except AttributeError:
+                have = None
+            want = _build.source_digest()
+            if have != want:
+                raise ImportError(f'{path} was built from other sources (digest {have and have[:12]} != {want[:12]}): rebuild with '
+                                  '`python -m tedm_amd.build` (or set TEDM_ALLOW_STALE_LIB=1 to load it anyway)')
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args

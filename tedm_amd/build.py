@@ -2,10 +2,13 @@
 
     python -m tedm_amd.build [--force]
 
-The library is rebuilt when any source under tedm_amd/csrc or include/ is newer than it.
+The library carries a digest of the sources it was built from (`tedm_source_digest()`, a generated translation unit): it is rebuilt
+when that digest differs from the digest of the sources on disk (or a source is newer than it), and `tedm_amd._lib` refuses to load a
+library whose digest does not match the tree it sits in -- a stale binary cannot pass for the current code, here or on a GPU box.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -32,11 +35,36 @@ def _deps() -> list:
     return sorted(CSRC.glob('*.hip')) + sorted(CSRC.glob('*.h')) + sorted(CSRC.glob('*.inc')) + sorted((ROOT / 'include').glob('*.h'))
 
 
+def source_digest() -> str:
+    """sha256 over (name, contents) of every file the library is compiled from, in sorted order."""
+    h = hashlib.sha256()
+    for p in _deps():
+        h.update(p.name.encode() + b'\0')
+        h.update(p.read_bytes())
+        h.update(b'\0')
+    return h.hexdigest()
+
+
+def library_digest(path: Path = LIB):
+    """The digest a built library reports, or None (missing library / symbol).  Loading needs no GPU."""
+    import ctypes
+    if not Path(path).exists():
+        return None
+    try:
+        fn = ctypes.CDLL(str(path)).tedm_source_digest
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in _deps())
+    if any(p.stat().st_mtime > t for p in _deps()):
+        return True
+    return library_digest() != source_digest()
 
 
 def _compile(src: str) -> Path:
@@ -60,6 +88,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             o.unlink()
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
+    # the digest translation unit (generated: not one of the hashed sources)
+    dsrc = OBJ / 'source_digest.cpp'
+    dsrc.write_text('extern "C" const char* tedm_source_digest(void) { return "%s"; }\n' % source_digest())
+    dobj = OBJ / 'source_digest.o'
+    r = subprocess.run([_hipcc(), '-O1', '-fPIC', '-c', '-x', 'c++', str(dsrc), '-o', str(dobj)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for the digest unit:\n{r.stdout}\n{r.stderr}')
+    objs.append(dobj)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

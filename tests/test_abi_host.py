@@ -30,6 +30,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert set(_lib.EXPORTED_SYMBOLS) == set(declared)
 
 
+def test_library_is_built_from_the_sources_next_to_it(built_lib, monkeypatch):
+    """The binary reports the digest of the sources it was compiled from; the loader compares it with the tree and refuses a
+    stale library instead of running old kernels under new host code (the .so is git-ignored and travels to the GPU box as built)."""
+    from tedm_amd import _lib, build
+    assert build.library_digest(built_lib) == build.source_digest()
+    assert not build.needs_build()
+    monkeypatch.setattr(build, 'source_digest', lambda: 'f' * 64)            # "someone edited a kernel and did not rebuild"
+    assert build.needs_build()
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(ImportError, match='built from other sources'):
+        _lib.lib()
+    monkeypatch.setenv('TEDM_ALLOW_STALE_LIB', '1')
+    assert _lib.lib() is not None
+
+
 def test_state_dict_contract(golden_dir):
     from tedm_amd import Unet
     want = json.loads((golden_dir / 'unet_d64_state_dict_keys.json').read_text())
