@@ -889,23 +889,35 @@ __global__ __launch_bounds__(256, 2) void la_qout_tail_kernel(LaTailArgs a) {
 //   M[d] = max_s m_s[d];  ctx[d][e] = sum_s ctx_s[d][e] w_s[d] / (hw * sum_s z_s[d] w_s[d]),  w_s[d] = exp(m_s[d] - M[d])
 __global__ __launch_bounds__(256) void la_ctx_merge_kernel(const float* __restrict__ part, int heads, int S, long long hw,
                                                            float* __restrict__ ctx) {
-    const int bh = blockIdx.x >> 2, b = bh / heads, head = bh - b * heads;      // 4 blocks per (sample, head)
-    const int i = (blockIdx.x & 3) * 256 + threadIdx.x, d = i >> 5;
+    // 16 blocks per (sample, head), 64 context entries each; the four waves of a block take every fourth partial (the loops are
+    // latency-bound: S / 4 dependent-free loads per lane instead of S) and are combined through LDS in a fixed order
+    __shared__ float sm[4][64], sc[4][64], sz[4][64];
+    const int bh = blockIdx.x >> 4, b = bh / heads, head = bh - b * heads;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = (blockIdx.x & 15) * 64 + lane, d = i >> 5;
     const size_t stride = (size_t)heads * 1088;
     const float* base = part + ((size_t)b * S * heads + head) * 1088;
-    // both loops are latency-bound (S dependent-free loads): unrolled by 8 so that eight loads are in flight per wait
     float M = -INFINITY;
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) M = fmaxf(M, base[s * stride + 1056 + d]);
+    for (int s = wv; s < S; s += 4) M = fmaxf(M, base[s * stride + 1056 + d]);
+    sm[wv][lane] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
     float c = 0.f, z = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) {
+    for (int s = wv; s < S; s += 4) {
         const float* cp = base + s * stride;
         const float w = __expf(cp[1056 + d] - M);
         c = fmaf(cp[i], w, c);
         z = fmaf(cp[1024 + d], w, z);
     }
-    ctx[(size_t)bh * 1024 + i] = c / (z * (float)hw);
+    sc[wv][lane] = c; sz[wv][lane] = z;
+    __syncthreads();
+    if (wv == 0) {
+        c = (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]);
+        z = (sz[0][lane] + sz[1][lane]) + (sz[2][lane] + sz[3][lane]);
+        ctx[(size_t)bh * 1024 + i] = c / (z * (float)hw);
+    }
 }
 
 // Tiles per workgroup / workgroups per image depend on the image size ONLY (never on B), so the
@@ -1003,7 +1015,7 @@ int op_linattn_qout_tail(const float* x, int C, const float* g, const float* lns
 }
 
 int op_linattn_ctx_merge(const float* partial, int B, int heads, int S, long long hw, float* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(la_ctx_merge_kernel, dim3(B * heads * 4), dim3(256), 0, st, partial, heads, S, hw, ctx);
+    hipLaunchKernelGGL(la_ctx_merge_kernel, dim3(B * heads * 16), dim3(256), 0, st, partial, heads, S, hw, ctx);
     return LAUNCH_OK();
 }
 

@@ -690,7 +690,9 @@ def test_default_datasetdm_features_and_head(dev, golden_dir):
     assert rel(f.mean(dim=(2, 3)), g['feats_mean']) < EPS_GATE
     with torch.no_grad():
         logits = dm.classifier(f)
-    assert rel(logits, g['logits']) < 5e-3
+    e = rel(logits, g['logits'])
+    print(f'default DatasetDM: logits vs the reference rel-L2 {e:.2e} (module default arithmetic {dm.diffusion_model.model.precision})')
+    assert e < 1e-4            # measured 1.3e-5 (was accepted up to 5e-3 until round 4)
 
 
 def test_loss_vs_golden(dev, golden_dir):
