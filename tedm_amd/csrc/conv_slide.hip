@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
             fa0[g % NB] = *(const u32x4*)(smem + abase[pr] + off);
             SL_SCHED();
         };
-        sl_for<SL_PF>([&](auto G) __attribute__((always_inline)) { read_group(G); });
+        // (lab builds without fragment reads in the band: every buffer is read once up front -- MFMAs on never-written registers
+        //  are undefined and were deleted by the compiler in round 4's first lab runs)
+        sl_for<((ABL & 8) ? NB : SL_PF)>([&](auto G) __attribute__((always_inline)) { read_group(G); });
         SL_SCHED();
         sl_for<48>([&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;
@@ -387,6 +389,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
                 }
             });
         });
+#ifdef SL_ABL        // lab builds without the epilogue: keep every accumulator live (round 4's first lab runs lost the MFMAs of phase 0 to
+                     // dead-code elimination -- the "MFMA only" figures of those runs are for half the MFMAs)
+        if constexpr ((ABL & 4) != 0) asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+#endif
         slot_e = wrap(slot_e + 8); slot_r = wrap(slot_r + 8);
         SL_STAMP(1);
         SL_STAMP(2);
