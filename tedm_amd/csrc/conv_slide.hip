@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
     }
 
 #ifdef SL_ABL        // tools/slide_lab.hip ablations (results wrong, timing only): 1 no encoder stages / loads in the band, 2 no output stores,
-                     // 4 no epilogue in the band at all, 8 no fragment reads behind the first groups
+                     // 4 no epilogue in the band at all.  (A switch "no fragment reads" existed in round 4's first lab runs and was
+                     // removed: with loop-invariant operands the compiler merges the two phases' identical MFMA chains, so it timed
+                     // half the MFMAs; every variant kept here has its 216 MFMAs per band in the ISA.)
     constexpr int ABL = SL_ABL;
 #else
     constexpr int ABL = 0;
@@ -254,9 +256,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
     const unsigned lane_off = (unsigned)(4 * h * 64 + cout);
     const int E = (H >> 2) * a.tiles_x;
     float s1 = 0.f, s2 = 0.f;
-#ifdef SL_FILL
-    float fill[8] = {0.f, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f};
-#endif
 
     // The band body is ONE straight-line block, written in the order it should issue: a wave alone on its SIMD overlaps nothing
     // by itself -- whatever VALU / LDS / VMEM work stands BETWEEN two MFMAs in program order runs in the first one's shadow
@@ -332,9 +331,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
             fa0[g % NB] = *(const u32x4*)(smem + abase[pr] + off);
             SL_SCHED();
         };
-        // (lab builds without fragment reads in the band: every buffer is read once up front -- MFMAs on never-written registers
-        //  are undefined and were deleted by the compiler in round 4's first lab runs)
-        sl_for<((ABL & 8) ? NB : SL_PF)>([&](auto G) __attribute__((always_inline)) { read_group(G); });
+        sl_for<SL_PF>([&](auto G) __attribute__((always_inline)) { read_group(G); });
         SL_SCHED();
         sl_for<48>([&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;
@@ -344,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
                 orow[0] = a.out + ((size_t)(n * H + oy) * W + tx * 32) * 64;
                 orow[1] = orow[0] + (size_t)W * 64;
             }
-            if constexpr (g + SL_PF < 48 && !(ABL & 8)) read_group(std::integral_constant<int, g + SL_PF>{});
+            if constexpr (g + SL_PF < 48) read_group(std::integral_constant<int, g + SL_PF>{});
             const f16x8 a0 = __builtin_bit_cast(f16x8, fa0[g % NB]), a1 = __builtin_bit_cast(f16x8, fa1[g % NB]);
             i32x8 a4 = {};
             a4[0] = faq[g % NB][0]; a4[1] = faq[g % NB][1]; a4[2] = faq[g % NB][2]; a4[3] = faq[g % NB][3];
@@ -380,10 +377,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
                         if constexpr (u % 3 == 1 && u / 3 < 32 && !(ABL & 4))
                             epi_value(std::integral_constant<int, ph ^ 1>{}, std::integral_constant<int, u / 3>{});
                         if constexpr (ph == 0 && u == 97) epi_stats(oyp);
-#ifdef SL_FILL      // tools/slide_lab.hip: SL_FILL independent VALU instructions behind every MFMA (what does an MFMA's shadow hide?)
-#pragma unroll
-                        for (int f = 0; f < SL_FILL; ++f) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fill[f % 8]) : "v"(bias));
-#endif
                         SL_SCHED();
                     });
                 }
@@ -399,9 +392,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_slide64_kernel(ConvArgs a, int
         __syncthreads();
         SL_STAMP(3);
     }
-#ifdef SL_FILL
-    if (a.trace && blockIdx.x == 0xffffff) for (int j = 0; j < 8; ++j) a.out[j] = fill[j];
-#endif
     // rows 2, 3 of the last band
     {
         const int oy = y0 + 8 * (nb - 1) + 4 * rh + 2;
@@ -446,12 +436,10 @@ void conv_slide_label(const ConvArgs& a, int pro, char* buf, int cap) {
 int conv_slide_launch(const ConvArgs& a_in, int pro, hipStream_t st) {
     ConvArgs a = a_in;
     a.tiles_x = a.W / 32;
-    // rows per workgroup: whole strips when that already fills the chip, else the largest divisor of H (multiple of 8, >= 16)
-    // that yields >= 256 workgroups
+    // rows per workgroup: conv_slide_common.h sl_pick_rows
     int rows = g_conv_slide_rows;
     if (rows <= 0 || rows % 8 || a.H % rows) {
-        rows = a.H;
-        while (rows > 16 && (long long)a.B * a.tiles_x * (a.H / rows) < 256 && rows % 16 == 0 && a.H % (rows / 2) == 0) rows /= 2;
+        rows = sl_pick_rows(a.B, a.H, a.tiles_x);
     }
     const bool st_on = a.stats_mode == STATS_SUMSQ;
     if (pro == PRO_GN) return st_on ? launch_slide<PRO_GN, true>(a, rows, st) : launch_slide<PRO_GN, false>(a, rows, st);

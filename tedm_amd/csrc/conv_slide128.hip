@@ -435,8 +435,7 @@ int conv_slide128_launch(const ConvArgs& a_in, hipStream_t st) {
     a.tiles_x = a.W / 32;
     int rows = g_conv_slide_rows;
     if (rows <= 0 || rows % 8 || a.H % rows) {
-        rows = a.H;
-        while (rows > 16 && (long long)a.B * a.tiles_x * (a.H / rows) < 256 && rows % 16 == 0 && a.H % (rows / 2) == 0) rows /= 2;
+        rows = sl_pick_rows(a.B, a.H, a.tiles_x);
     }
     return a.stats_mode == STATS_SUMSQ ? launch_slide128<true>(a, rows, st) : launch_slide128<false>(a, rows, st);
 }

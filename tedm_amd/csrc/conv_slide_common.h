@@ -36,3 +36,20 @@ constexpr int SL_SEG = (SL_HC + 1) * SL_PST;  // one ring row of one chunk: 34 r
                                              // the stores of the columns outside the image, whose own records stay zero)
 
 }  // namespace
+
+// Rows of the image one workgroup walks (both sliding-window kernels; one workgroup per CU).  The kernel's time is
+// (rounds of 256 workgroups) x (rows per workgroup + the ~10 rows a workgroup encodes before its first band), so among the divisors
+// H, H/2, H/4, ... (multiples of 8, >= 16) the one that minimises that product wins: whole strips when B x column tiles is a multiple
+// of the CU count (B = 32 at 256^2), shorter strips when whole ones would leave a partial round (B = 33, 48) or an empty chip
+// (B = 1).  Every choice gives the same bits (a strip boundary only moves the rows a workgroup encodes twice).
+inline int sl_pick_rows(int B, int H, int tiles_x, int cus = 256) {
+    int best = H;
+    long long best_cost = -1;
+    for (int rows = H; rows >= 16 && rows % 8 == 0 && H % rows == 0; rows /= 2) {
+        const long long wgs = (long long)B * tiles_x * (H / rows), rounds = (wgs + cus - 1) / cus;
+        const long long cost = rounds * (rows + 10);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rows; }
+        if (rows % 16) break;
+    }
+    return best;
+}

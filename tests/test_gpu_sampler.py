@@ -33,7 +33,9 @@ def run_step(dm, x_t, out, t, noise, objective, clip=True):
     return x0, mean, prev, s
 
 
-@pytest.mark.parametrize('shape', [(5, 1, 256, 256), (3, 3, 40, 24), (2, 1, 8, 8)])
+# (5,1,256,256) and the small shapes take the register-resident selection (<= 64 K values per sample), (3,2,256,192) = 96 K values the
+# LDS-histogram kernel kept for larger samples
+@pytest.mark.parametrize('shape', [(5, 1, 256, 256), (3, 3, 40, 24), (2, 1, 8, 8), (3, 2, 256, 192)])
 def test_sampler_step_kernel_vs_torch_ops(dev, shape):
     from argparse import Namespace
     from tedm_amd import DiffusionModel

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measurement set under profiles/ on a GPU box (one MI355X):  bash tools/refresh_profiles.sh r02a
 # Writes scratch under gpurun_out/ and copies the judged summaries to profiles/<tag>_*.
-set -e
+set -e -o pipefail
 set -x          # progress on stderr: a GPU box kills a command that stays silent for 7 minutes
 tag=${1:?usage: refresh_profiles.sh <tag>}
 cd "$(dirname "$0")/.."

@@ -47,41 +47,8 @@ namespace g3 {
 #undef SL_GAPMODE
 #undef SL_ABL
 }
-namespace f2 {
-#define SL_ABL 13
-#define SL_FILL 2
-#include "conv_slide.hip"
-#undef SL_FILL
-#undef SL_ABL
-}
-namespace f4 {
-#define SL_ABL 13
-#define SL_FILL 4
-#include "conv_slide.hip"
-#undef SL_FILL
-#undef SL_ABL
-}
-namespace f6 {
-#define SL_ABL 13
-#define SL_FILL 6
-#include "conv_slide.hip"
-#undef SL_FILL
-#undef SL_ABL
-}
-namespace f8 {
-#define SL_ABL 13
-#define SL_FILL 8
-#include "conv_slide.hip"
-#undef SL_FILL
-#undef SL_ABL
-}
 namespace x5 {
 #define SL_ABL 5
-#include "conv_slide.hip"
-#undef SL_ABL
-}
-namespace x13 {
-#define SL_ABL 13
 #include "conv_slide.hip"
 #undef SL_ABL
 }
@@ -168,11 +135,6 @@ int main(int argc, char** argv) {
                              {"no stores, rows 256", x2::conv_slide_launch, 256, &x2::g_conv_slide_rows},
                              {"neither, rows 256", x3::conv_slide_launch, 256, &x3::g_conv_slide_rows},
                              {"mfma + lds reads only", x5::conv_slide_launch, 256, &x5::g_conv_slide_rows},
-                             {"mfma only", x13::conv_slide_launch, 256, &x13::g_conv_slide_rows},
-                             {"mfma only + 2 VALU/gap", f2::conv_slide_launch, 256, &f2::g_conv_slide_rows},
-                             {"mfma only + 4 VALU/gap", f4::conv_slide_launch, 256, &f4::g_conv_slide_rows},
-                             {"mfma only + 6 VALU/gap", f6::conv_slide_launch, 256, &f6::g_conv_slide_rows},
-                             {"mfma only + 8 VALU/gap", f8::conv_slide_launch, 256, &f8::g_conv_slide_rows},
 #endif
         };
         std::vector<std::vector<float>> t(vs.size());
