@@ -29,6 +29,8 @@ SLIDE_CASES = [
     (64, 40, 96, 3, 1, 0, 8),       # H not a power of two, one band per workgroup, no statistics
     (64, 128, 64, 1, 0, 1, 32),
     (64, 256, 256, 2, 1, 1, 0),     # the benchmark geometry at a small batch
+    (64, 128, 128, 9, 1, 1, 0),     # odd batch: the automatic strip length avoids a partial round of workgroups (sl_pick_rows)
+    (64, 64, 256, 5, 0, 1, 0),
 ]
 
 
@@ -57,7 +59,7 @@ def test_slide_equals_tiled_kernel(lib, dev, case):
 
 
 # H, W, B, stats, rows per workgroup
-SLIDE128_CASES = [(16, 32, 1, 1, 0), (64, 64, 2, 1, 0), (40, 96, 2, 0, 8), (64, 64, 2, 1, 64), (256, 256, 1, 1, 128)]
+SLIDE128_CASES = [(16, 32, 1, 1, 0), (64, 64, 2, 1, 0), (40, 96, 2, 0, 8), (64, 64, 2, 1, 64), (256, 256, 1, 1, 128), (64, 128, 5, 1, 0)]
 
 
 @pytest.mark.parametrize('case', SLIDE128_CASES, ids=lambda c: '{}x{}_b{}_st{}_r{}'.format(*c))
