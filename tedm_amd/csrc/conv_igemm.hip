@@ -72,6 +72,17 @@ inline TileSel tile_geom(int id, int stride) {
 }
 
 int g_conv_small_grid = 1;   // tedm_set_tuning("conv_small_grid", 0|1)
+int g_conv_upw = 1;          // tedm_set_tuning("conv_upw", 0|1): the x2-upsample parity convs with the parity on the wave (PAD = -2 instances)
+
+// The x2-upsample parity convs (ups == 3) with one parity per WAVE: 1x8-wave tile of 8 rows, 4 rows when that fills the chip better,
+// -1 = keep one parity per tile (small grids).  The choice depends on the shape and B like every tile choice; all forms accumulate
+// each output's taps and chunks in the same order (same bits).
+inline int upw_tile(const ConvArgs& a) {
+    if (!g_conv_upw || a.add || a.stats_mode != STATS_NONE || a.out_q16 || a.add_q16) return -1;
+    const int CT = (a.Cout + 31) / 32, ny = (4 * CT + 7) / 8;
+    auto wgs = [&](int rows) { return (long long)a.B * ((a.H + rows - 1) / rows) * ((a.W + 31) / 32) * ny; };
+    return wgs(8) >= 256 ? 5 : (wgs(4) >= 256 ? 4 : -1);
+}
 
 // Small batches (the sampler, single images): when the default tile would launch fewer workgroups than the chip has CUs, halve the
 // rows (tall256 -> wide256), then the output channels per workgroup.  The statistics slab is per 4 output rows whatever the tile
@@ -104,6 +115,7 @@ int conv_set_tuning(const char* key, int v) {
     if (!strcmp(key, "conv_xcd_order") && (v == 0 || v == 1)) { g_conv_xcd_order = v; return TEDM_OK; }
     if (!strcmp(key, "conv_tile_narrow") && ((v >= 0 && v <= 3) || v == 6)) { g_tile_narrow = v; return TEDM_OK; }
     if (!strcmp(key, "conv_small_grid") && (v == 0 || v == 1)) { g_conv_small_grid = v; return TEDM_OK; }
+    if (!strcmp(key, "conv_upw") && (v == 0 || v == 1)) { g_conv_upw = v; return TEDM_OK; }
     if (!strcmp(key, "conv_slide") && (v == 0 || v == 1)) { g_conv_slide = v; return TEDM_OK; }
     if (!strcmp(key, "conv_slide_rows") && v >= 0 && v % 8 == 0) { g_conv_slide_rows = v; return TEDM_OK; }
     return TEDM_EINVAL;
@@ -121,7 +133,11 @@ void conv_kernel_label(const ConvArgs& a, int KH, int stride, int ups, int pro, 
                       ks, nbuf, pro, a.prec, qio);
     else snprintf(buf, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", KH, KH, stride, pad, ups, t.wm, t.wn, t.mt,
                   ks, nbuf, pro, a.prec);
-    if (ups == 3) snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-1,0,%d,%d,%d,%d,2,%d,%d>", t.wm, t.wn, t.mt, ks, pro, a.prec);
+    if (ups == 3) {
+        const int tw = (KH == 2 && !a.x2) ? upw_tile(a) : -1;
+        if (tw >= 0) snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-2,0,1,8,%d,%d,2,%d,%d>", tw == 5 ? 8 : 4, ks, pro, a.prec);
+        else snprintf(buf, cap, "conv_igemm_kernel<2,2,1,-1,0,%d,%d,%d,%d,2,%d,%d>", t.wm, t.wn, t.mt, ks, pro, a.prec);
+    }
 }
 
 int conv_stats_entries(int KH, int stride, int Cout, int Ho, int Wo) {
@@ -144,14 +160,16 @@ int conv_launch(const ConvArgs& a_in, int KH, int stride, int ups, int pro, hipS
     if (KH == 1 && (a.C1 % 32 || a.C2 % 32)) return TEDM_EINVAL;   // 1x1 stages 32-channel chunks
     if (conv_slide_supported(a, KH, stride, ups, pro)) return conv_slide_launch(a, pro, st);
     if (conv_slide128_supported(a, KH, stride, ups, pro)) return conv_slide128_launch(a, st);
-    const int tile_id = effective_tile(a, KH, stride, ups, pro);
-    const TileSel t = tile_geom(tile_id, stride);
-    const int TR = t.wm * t.mt;
+    int tile_id = effective_tile(a, KH, stride, ups, pro);
     if (ups == 3) {                                               // parity convs: the kernel's grid is the low-resolution one
         if (KH != 2 || a.Ho != 2 * a.H || a.Wo != 2 * a.W || a.stats_mode != STATS_NONE || a.x2) return TEDM_EINVAL;
+        const int tw = upw_tile(a);
+        if (tw >= 0) { ups = 4; tile_id = tw; }                   // parity per wave (conv_igemm.inc PAD = -2)
         a.Ho = a.H; a.Wo = a.W;
         a.wpk_pstride = conv_packed_bytes(a.Cout, Cin, 4);
     }
+    const TileSel t = tile_geom(tile_id, stride);
+    const int TR = t.wm * t.mt;
     a.tiles_y = (a.Ho + TR - 1) / TR;
     a.tiles_x = (a.Wo + 31) / 32;
     a.nk16 = Cin / 16;

@@ -220,6 +220,36 @@ def test_upconv_parity_form(lib, dev, case, prec):
     assert torch.equal(out3, out)                      # bitwise reproducible
 
 
+# Cin, Cout, H, W, B: grids of >= 256 workgroups, where the dispatch gives every WAVE one parity (conv_igemm.inc PAD = -2: the halo
+# is staged once for the four parities); 8-row and 4-row tiles, ragged heights / widths, one and two workgroups per spatial tile
+UPW_CASES = [(64, 64, 128, 64, 8), (64, 64, 50, 72, 12), (128, 64, 64, 64, 8), (128, 128, 60, 64, 5), (256, 128, 32, 32, 16), (512, 256, 16, 32, 16)]
+
+
+@pytest.mark.parametrize('prec', [3, 0], ids=['f16f4', 'bf16x3'])
+@pytest.mark.parametrize('case', UPW_CASES, ids=lambda c: '{}to{}_{}x{}_b{}'.format(*c))
+def test_upconv_parity_per_wave(lib, dev, case, prec):
+    """The x2-upsample conv with the parity on the wave against the one-parity-per-tile form of the same kernel (BIT FOR BIT: both
+    accumulate an output's taps and channel chunks in the same order) and against fp64."""
+    from tedm_amd import _lib
+    Cin, Cout, H, W, B = case
+    x = rnd(B, Cin, H, W, seed=31)
+    w = rnd(Cout, Cin, 3, 3, seed=32, scale=(1.0 / (Cin * 9)) ** 0.5)
+    b = rnd(Cout, seed=33, scale=0.1)
+    labels = []
+    try:
+        _lib.check(lib.tedm_set_tuning(b'conv_upw', 0))
+        ref_out, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=3, prec=prec)
+        _lib.check(lib.tedm_set_tuning(b'conv_upw', 1))
+        out, _ = run_conv(lib, dev, x, None, w, b, 3, 1, ups=3, prec=prec)
+    finally:
+        _lib.check(lib.tedm_set_tuning(b'conv_upw', 1))
+    assert torch.isfinite(out).all()                   # every output pixel written (the buffer starts as NaN)
+    bad = out != ref_out
+    assert not bad.any(), f'{int(bad.sum())} of {bad.numel()} outputs differ, first at {bad.nonzero()[0].tolist()}'
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest').double(), w.double(), b.double(), padding=1)
+    assert rel(out, ref) < (F4_TOL if prec == 3 else KERNEL_TOL)
+
+
 def test_upconv_parity_identity(lib, dev):
     """Exact check of the tap grouping and the output interleave: unit weights on one tap, small-integer data."""
     B, Cc, H, W = 1, 64, 10, 35
@@ -233,6 +263,15 @@ def test_upconv_parity_identity(lib, dev):
             for prec in (3, 0):
                 out, _ = run_conv(lib, dev, x, None, w, None, 3, 1, ups=3, prec=prec)
                 assert torch.equal(out, F.conv2d(up, w, None, padding=1)), (ky, kx, prec)
+    # the same at a batch that takes the parity-per-wave instances (>= 256 workgroups)
+    xb = x.repeat(96, 1, 1, 1) + torch.arange(96, dtype=torch.float32).view(96, 1, 1, 1)
+    upb = F.interpolate(xb, scale_factor=2, mode='nearest')
+    for ky, kx in ((0, 0), (1, 2), (2, 1)):
+        w = torch.zeros(Cc, Cc, 3, 3)
+        for o in range(Cc):
+            w[o, (o * 5 + 1) % Cc, ky, kx] = 1.0
+        out, _ = run_conv(lib, dev, xb, None, w, None, 3, 1, ups=3, prec=3)
+        assert torch.equal(out, F.conv2d(upb, w, None, padding=1)), (ky, kx)
 
 
 def test_conv_f16f4_scales_and_ranges(lib, dev):
