@@ -406,16 +406,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
     for (; tl + 1 < t_end; tl += 2) { tile(tl, R0); tile(tl + 1, R1); }
     if (tl < t_end) tile(tl, R0);
 
+    // The two column groups of the workgroup hold partials of the SAME (co, ci, tap) block: the right group hands its
+    // accumulators to the left one through LDS (lane-contiguous rows: conflict-free) and ONE partial per pixel split is written --
+    // half the partial traffic of the bf16x3 kernel, for this kernel's epilogue and for the reduce pass behind it
+    __syncthreads();                                   // every wave is done with the staging buffers
+    float* xs = (float*)smem + (size_t)(wave & 3) * 9 * 16 * 64;
+    if (cg == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xs[(t * 16 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (cg == 1) return;
     const float inv = amax ? f16_plane_scale(*amax, true) : 1.f;
     const int ci = ci0 + wi * 32 + r;
-    const size_t sp = (size_t)split * 2 + cg;
+    const size_t sp = (size_t)split;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = co0 + wc * 32 + acc_row(i, h);
+            const float v = (acc[t][i] + xs[(t * 16 + i) * 64 + lane]) * inv;
             if (co < a.Cout && ci < a.Cin)
-                a.part[((sp * 9 + t) * a.Cout + co) * a.Cin + ci] = acc[t][i] * inv;
+                a.part[((sp * 9 + t) * a.Cout + co) * a.Cin + ci] = v;
         }
     }
 }
@@ -510,8 +524,15 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
         WgArgs a{};
         a.dyh = dyh; a.xh = xh; a.Cout = Cout; a.Cin = Cin; a.B = B; a.Hp = g.Hp;
         a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.part = ws; a.S = g.S; a.tpw = g.tpw; a.nci_blk = g.nci; a.nblk = g.nco * g.nci;
-        *S_out = 2 * g.S;
-        const size_t lds = (size_t)64 * (144 + 336);
+        *S_out = g.S;                                  // (the kernel merges its two column groups)
+        const size_t lds = (size_t)4 * 9 * 16 * 64 * 4;        // the exchange of the column groups (147 456 B) covers the staging buffers
+        static bool attr16[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return TEDM_EHIP;
+        if (dev < 0 || dev >= 16 || !attr16[dev]) {
+            if (hipFuncSetAttribute((const void*)wgrad_mfma8_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEDM_EHIP;
+            if (dev >= 0 && dev < 16) attr16[dev] = true;
+        }
         hipLaunchKernelGGL(wgrad_mfma8_f16_kernel, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, amax);
         return LAUNCH_OK();
     }
