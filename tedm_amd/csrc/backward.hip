@@ -331,7 +331,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     if (amax) {      // (an integer maximum: order independent, the result is deterministic; consumed by the fp16 weight gradient)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o));
-        if (lane == 0 && am) atomicMax(amax, am);
+        // 16 K same-address atomics serialise in L2 (measured: +80 us per launch): one per workgroup, and only when it can still
+        // raise the value (a stale read only costs a redundant atomic: the maximum is monotonic)
+        __shared__ unsigned wmax[4];
+        if (lane == 0) wmax[threadIdx.x >> 6] = am;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            am = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+            if (am > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, am);
+        }
     }
 }
 

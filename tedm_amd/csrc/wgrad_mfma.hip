@@ -69,7 +69,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per workgroup, and only when it can still raise the value (same-address atomics serialise in L2)
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    }
 }
 
 TEDM_DEVFN uint32_t bf16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v); }
