@@ -315,9 +315,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_kernel(WgArgs a) {
 // The single-fp16-product instance: same geometry, only the "hi" planes exist (dY scaled, see the header), 18 MFMAs per tile
 // instead of 54 and half the bytes -- so the plane loads run TWO tiles ahead (register sets R0 / R1, the loop body is a pair of
 // tiles) to keep the bytes in flight the bf16x3 kernel has with one.  Partials are scaled back by the exact inverse scale.
+template <int TRF>
 __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const unsigned* __restrict__ amax) {
-    constexpr int HR = TR + 2, XCH = 5, XS = 336, DS = 144;
-    constexpr int NX = 64 * HR * XCH;
+    // FOUR output rows per tile (the bf16x3 kernel: two): 36 MFMAs between the two barriers of a tile instead of 18, and 6 halo rows
+    // of X per 4 rows instead of 4 per 2 (a quarter less X traffic)
+    constexpr int TR = TRF;
+    constexpr int HR = TR + 2, XCH = 5, XS = HR * XCH * 16 + 16, DS = TR * 64 + 16;     // odd multiples of 16 B: conflict-free b128 reads
+    constexpr int NDY = 64 * TR * 4, NX = 64 * HR * XCH;         // 16-byte chunks per tile: 1024 / 1920
+    constexpr int ND = NDY / 512, NXI = (NX + 511) / 512;        // items per thread: 2 / 4
+    static_assert(NDY % 512 == 0 && (XS / 16) % 2 == 1 && (DS / 16) % 2 == 1, "staging geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sdy = smem;
     char* sx = sdy + 64 * DS;
@@ -334,18 +340,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
     const int t_beg = split * a.tpw, t_end = (t_beg + a.tpw < ntile) ? t_beg + a.tpw : ntile;
     const unsigned dy_row = (unsigned)a.tiles_x * a.Cout * 32, x_row = (unsigned)a.tiles_x * a.Cin * 40;
 
-    unsigned g_dy0, g_x[3];
-    int l_dy0, l_x[3];
-    uint32_t m_dy0, m_x[3];
-    {
-        const int row = tid >> 8, rem = tid & 255, c = rem >> 2, q = rem & 3;
+    unsigned g_dy[ND], g_x[NXI];
+    int l_dy[ND], l_x[NXI];
+    uint32_t m_dy[ND], m_x[NXI];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int i = tid + 512 * j;
+        const int row = i >> 8, rem = i & 255, c = rem >> 2, q = rem & 3;
         const int ch = co0 + c;
-        m_dy0 = ch < a.Cout ? ~0u : 0u;
-        g_dy0 = (unsigned)(1 + row) * dy_row + (unsigned)(ch < a.Cout ? ch : a.Cout - 1) * 32 + q * 8;
-        l_dy0 = c * DS + row * 64 + q * 16;
+        m_dy[j] = ch < a.Cout ? ~0u : 0u;
+        g_dy[j] = (unsigned)(1 + row) * dy_row + (unsigned)(ch < a.Cout ? ch : a.Cout - 1) * 32 + q * 8;
+        l_dy[j] = c * DS + row * 64 + q * 16;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NXI; ++j) {
         const int i = tid + 512 * j, ic = i < NX ? i : NX - 1;
         const int row = ic / 320, rem = ic - row * 320, c = rem / 5, q = rem - c * 5;
         const int ch = ci0 + c;
@@ -353,15 +361,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
         g_x[j] = (unsigned)row * x_row + (unsigned)(ch < a.Cin ? ch : a.Cin - 1) * 40 + q * 8;
         l_x[j] = c * XS + row * (XCH * 16) + q * 16;
     }
-    struct Regs { uint4 d, x0, x1, x2; };
+    struct Regs { uint4 d[ND], x[NXI]; };
     auto issue = [&](int tl, Regs& R) __attribute__((always_inline)) {
         const int tc = tl < t_end ? tl : t_end - 1;                      // past the end: an unused re-load (branch-free loop)
         const int n_ = tc / tpi, trem_ = tc - n_ * tpi;
         const int tx_ = trem_ / a.tiles_y, ty_ = trem_ - tx_ * a.tiles_y;
         const size_t rowb = (size_t)(n_ * a.Hp + ty_ * TR) * a.tiles_x + tx_;
         const uint16_t *bdy = a.dyh + rowb * a.Cout * 32, *bx = a.xh + rowb * a.Cin * 40;
-        R.d = *(const uint4*)(bdy + g_dy0);
-        R.x0 = *(const uint4*)(bx + g_x[0]); R.x1 = *(const uint4*)(bx + g_x[1]); R.x2 = *(const uint4*)(bx + g_x[2]);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) R.d[j] = *(const uint4*)(bdy + g_dy[j]);
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) R.x[j] = *(const uint4*)(bx + g_x[j]);
     };
     auto put = [&](char* base, int off, const uint4& v, uint32_t m) __attribute__((always_inline)) {
         u32x4 w = {v.x & m, v.y & m, v.z & m, v.w & m};
@@ -378,8 +388,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
 
     auto tile = [&](int tl, Regs& R) __attribute__((always_inline)) {
         __syncthreads();                               // every wave is done reading the previous tile
-        put(sdy, l_dy0, R.d, m_dy0);
-        put(sx, l_x[0], R.x0, m_x[0]); put(sx, l_x[1], R.x1, m_x[1]); put(sx, l_x[2], R.x2, m_x[2]);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) put(sdy, l_dy[j], R.d[j], m_dy[j]);
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) put(sx, l_x[j], R.x[j], m_x[j]);
         __syncthreads();
         issue(tl + 2, R);                              // in flight during this tile's and the next tile's MFMAs
         f16x8 av[TR];
@@ -443,11 +455,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma8_f16_kernel(WgArgs a, const
 
 int g_wgrad_splits = 512;     // tedm_set_tuning("wgrad_splits", n): pixel splits x channel blocks aimed at (n workgroups = n / 256 rounds of one per CU)
 struct Geo { int tiles_x, tiles_y, Hp, S, tpw, nco, nci; };
-Geo geometry(int Cout, int Cin, int B, int Ho, int Wo) {
+constexpr int TR16 = 4;   // output rows per tile of the single-fp16-product kernel
+Geo geometry(int Cout, int Cin, int B, int Ho, int Wo, int tr = TR) {
     Geo g;
     g.tiles_x = (Wo + 31) / 32;
-    g.tiles_y = (Ho + TR - 1) / TR;
-    g.Hp = g.tiles_y * TR + 2;
+    g.tiles_y = (Ho + tr - 1) / tr;
+    g.Hp = g.tiles_y * tr + 2;
     g.nco = (Cout + 63) / 64;
     g.nci = (Cin + 63) / 64;
     const long long ntile = (long long)B * g.tiles_x * g.tiles_y;
@@ -496,7 +509,12 @@ size_t wgrad_mfma_floats(int k, int Cout, int Cin, int B, int Ho, int Wo) {
     const Geo g = geometry(Cout, Cin, B, Ho, Wo);
     const size_t part = ((size_t)g.S * 2 * 9 * Cout * Cin + 63) & ~(size_t)63;
     const size_t planes = (plane_elems(g, B, Cout, 32) + plane_elems(g, B, Cin, 40)) * 2;    // hi + lo, 2 bytes each
-    return part + (planes * 2 + 3) / 4 + 64;
+    const size_t n2 = part + (planes * 2 + 3) / 4 + 64;
+    // the single-fp16-product layout (4-row tiles, one plane per operand, one partial per split, 64 floats for the maximum)
+    const Geo h = geometry(Cout, Cin, B, Ho, Wo, TR16);
+    const size_t part16 = ((size_t)h.S * 9 * Cout * Cin + 63) & ~(size_t)63;
+    const size_t n16 = part16 + 64 + ((plane_elems(h, B, Cout, 32) + plane_elems(h, B, Cin, 40)) * 2 + 3) / 4 + 64;
+    return n2 > n16 ? n2 : n16;
 }
 
 // 3x3, stride 1, prologue NONE or GN.  ups: the conv read the nearest-x2 upsampled input (H,W are the SOURCE size, Ho=2H).
@@ -514,33 +532,39 @@ int op_conv_wgrad_mfma(const float* dy, int Cout, const float* x1, int C1, const
     uint16_t* xh = dyl + ndy;
     uint16_t* xl = xh + nx;
     if (f16) {
-        // (the planes of the bf16x3 layout are reserved either way: dyl's first word holds the maximum, xh stays where it is)
+        // layout: [partials S x 9 x Cout x Cin | 64 floats: the maximum | dY plane | X plane], 4-row tiles
+        const Geo h = geometry(Cout, Cin, B, Ho, Wo, TR16);
+        const size_t part16 = ((size_t)h.S * 9 * Cout * Cin + 63) & ~(size_t)63;
+        const size_t ndy16 = plane_elems(h, B, Cout, 32), nx16 = plane_elems(h, B, Cin, 40);
+        if (ndy16 >= (1ull << 31) || nx16 >= (1ull << 31)) return TEDM_EINVAL;
+        unsigned* am = (unsigned*)(ws + part16);
+        uint16_t* dy16 = (uint16_t*)(ws + part16 + 64);
+        uint16_t* x16 = dy16 + ((ndy16 + 7) & ~(size_t)7);
         const unsigned* amax = dy_amax;
         if (!amax) {                                   // the producer of dY did not track it: one more pass over dY
-            unsigned* am = (unsigned*)dyl;
             if (hipMemsetAsync(am, 0, 4, st) != hipSuccess) return TEDM_EHIP;
             const long long n4 = (long long)B * Ho * Wo * Cout / 4;
             const int nb = (int)((n4 + 256 * 8 - 1) / (256 * 8) < 2048 ? (n4 + 256 * 8 - 1) / (256 * 8) : 2048);
             hipLaunchKernelGGL(absmax_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, (const float4*)dy, n4, am);
             amax = am;
         }
-        int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, nullptr, g, st, true, amax);
+        int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dy16, nullptr, h, st, true, amax);
         if (rc != TEDM_OK) return rc;
-        rc = launch_planar(x1, C1, x2, C2, B, H, W, Ho, Wo, ups, 1, pro, pro_a, pro_b, xh, nullptr, g, st, true, nullptr);
+        rc = launch_planar(x1, C1, x2, C2, B, H, W, Ho, Wo, ups, 1, pro, pro_a, pro_b, x16, nullptr, h, st, true, nullptr);
         if (rc != TEDM_OK) return rc;
         WgArgs a{};
-        a.dyh = dyh; a.xh = xh; a.Cout = Cout; a.Cin = Cin; a.B = B; a.Hp = g.Hp;
-        a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.part = ws; a.S = g.S; a.tpw = g.tpw; a.nci_blk = g.nci; a.nblk = g.nco * g.nci;
-        *S_out = g.S;                                  // (the kernel merges its two column groups)
-        const size_t lds = (size_t)4 * 9 * 16 * 64 * 4;        // the exchange of the column groups (147 456 B) covers the staging buffers
+        a.dyh = dy16; a.xh = x16; a.Cout = Cout; a.Cin = Cin; a.B = B; a.Hp = h.Hp;
+        a.tiles_x = h.tiles_x; a.tiles_y = h.tiles_y; a.part = ws; a.S = h.S; a.tpw = h.tpw; a.nci_blk = h.nci; a.nblk = h.nco * h.nci;
+        *S_out = h.S;                                  // (the kernel merges its two column groups)
+        const size_t lds = (size_t)4 * 9 * 16 * 64 * 4;        // the exchange of the column groups (147 456 B) covers the staging buffers (49 KB)
         static bool attr16[16] = {};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return TEDM_EHIP;
         if (dev < 0 || dev >= 16 || !attr16[dev]) {
-            if (hipFuncSetAttribute((const void*)wgrad_mfma8_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEDM_EHIP;
+            if (hipFuncSetAttribute((const void*)wgrad_mfma8_f16_kernel<TR16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TEDM_EHIP;
             if (dev >= 0 && dev < 16) attr16[dev] = true;
         }
-        hipLaunchKernelGGL(wgrad_mfma8_f16_kernel, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, amax);
+        hipLaunchKernelGGL(wgrad_mfma8_f16_kernel<TR16>, dim3(8 * ((a.S + 7) / 8) * a.nblk), dim3(512), lds, st, a, amax);
         return LAUNCH_OK();
     }
     int rc = launch_planar(dy, Cout, nullptr, 0, B, Ho, Wo, Ho, Wo, 0, 0, PRO_NONE, nullptr, nullptr, dyh, dyl, g, st);
