@@ -61,53 +61,89 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (int tl = t_beg; tl < t_end; ++tl) {
-        const int n = tl / tpi;
-        const int trem = tl - n * tpi;
+    // Staging is software-pipelined: the global loads of tile t + 1 are issued into registers before the MFMAs of tile t and
+    // committed to LDS (prologue, masks) after them.  (Loading and computing in turn left the kernel waiting for HBM every tile:
+    // the 64 -> 384 qkv gradient took 1.6 ms at 256^2 where its fp32 MFMAs need 0.75 ms.)
+    constexpr int NDI = (NPX * 16 + 255) / 256, NXI = (NHP * 16 + 255) / 256;     // float4 items per thread: dY / X
+    float4 rdy[NDI], rxv[NXI];
+    float2 rst[PRO == PRO_LN ? NXI : 1];
+    bool okd[NDI], okx[NXI];
+    auto issue = [&](int tl) __attribute__((always_inline)) {
+        const int tc = tl < t_end ? tl : t_end - 1;               // past the end: an unused re-load (branch-free loop)
+        const int n = tc / tpi;
+        const int trem = tc - n * tpi;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int oy0 = ty * TR, ox0 = tx * 32;
         const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
-        __syncthreads();                               // previous tile's MFMAs are done with the LDS
-        // ---- stage dY tile: NPX x 16 float4 (unconditional loads, clamped address, masked value) ----
-        for (int i = tid; i < NPX * 16; i += 256) {
-            const int px = i >> 4, c4 = (i & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int i = tid + 256 * k;
+            const int ic = i < NPX * 16 ? i : NPX * 16 - 1;
+            const int px = ic >> 4, c4 = (ic & 15) * 4;
             const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
-            const bool ok = oy < a.Ho && ox < a.Wo && co0 + c4 < a.Cout;
+            okd[k] = oy < a.Ho && ox < a.Wo && co0 + c4 < a.Cout;
             const int oyc = oy < a.Ho ? oy : a.Ho - 1, oxc = ox < a.Wo ? ox : a.Wo - 1;
             const int cc = co0 + c4 < a.Cout ? co0 + c4 : 0;
-            float4 v = *(const float4*)(a.dy + ((size_t)(n * a.Ho + oyc) * a.Wo + oxc) * a.Cout + cc);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *(float4*)(sdy + px * 64 + c4) = v;
+            rdy[k] = *(const float4*)(a.dy + ((size_t)(n * a.Ho + oyc) * a.Wo + oxc) * a.Cout + cc);
         }
-        // ---- stage haloed X tile through the forward conv's prologue ----
-        for (int i = tid; i < NHP * 16; i += 256) {
-            const int hp = i >> 4, c4 = (i & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int i = tid + 256 * k;
+            const int ic = i < NHP * 16 ? i : NHP * 16 - 1;
+            const int hp = ic >> 4, c4 = (ic & 15) * 4;
             const int hy = hp / HC, hx = hp - hy * HC;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const int ch = ci0 + c4;
-            const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win && ch < Cin;
+            okx[k] = iy >= 0 && iy < Hin && ix >= 0 && ix < Win && ch < Cin;
             int sy = UPS ? (iy >> 1) : iy, sxx = UPS ? (ix >> 1) : ix;
             sy = sy < 0 ? 0 : (sy >= a.H ? a.H - 1 : sy);
             sxx = sxx < 0 ? 0 : (sxx >= a.W ? a.W - 1 : sxx);
             const int chc = ch < Cin ? ch : 0;
             const size_t gp = (size_t)(n * a.H + sy) * a.W + sxx;
             const float* src = chc < a.C1 ? a.x1 + gp * a.C1 + chc : a.x2 + gp * a.C2 + (chc - a.C1);
-            float4 v = *(const float4*)src;
-            if (PRO == PRO_GN) {
-                const float4 pa = *(const float4*)(a.pro_a + (size_t)n * Cin + chc);
-                const float4 pb = *(const float4*)(a.pro_b + (size_t)n * Cin + chc);
-                v.x = silu_f(fmaf(pa.x, v.x, pb.x)); v.y = silu_f(fmaf(pa.y, v.y, pb.y));
-                v.z = silu_f(fmaf(pa.z, v.z, pb.z)); v.w = silu_f(fmaf(pa.w, v.w, pb.w));
-            } else if (PRO == PRO_LN) {
-                const float4 g = *(const float4*)(a.pro_a + chc);
-                const float2 st2 = *(const float2*)(a.pro_b + gp * 2);
-                v.x = g.x * (v.x * st2.x - st2.y); v.y = g.y * (v.y * st2.x - st2.y);
-                v.z = g.z * (v.z * st2.x - st2.y); v.w = g.w * (v.w * st2.x - st2.y);
-            }
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *(float4*)(sx + hp * 64 + c4) = v;
+            rxv[k] = *(const float4*)src;
+            if (PRO == PRO_LN) rst[k] = *(const float2*)(a.pro_b + gp * 2);
         }
+    };
+    auto commit = [&](int tl) __attribute__((always_inline)) {
+        const int n = tl / tpi;
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NPX * 16) {
+                const int px = i >> 4, c4 = (i & 15) * 4;
+                *(float4*)(sdy + px * 64 + c4) = okd[k] ? rdy[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NHP * 16) {
+                const int hp = i >> 4, c4 = (i & 15) * 4;
+                const int ch = ci0 + c4, chc = ch < Cin ? ch : 0;
+                float4 v = rxv[k];
+                if (PRO == PRO_GN) {
+                    const float4 pa = *(const float4*)(a.pro_a + (size_t)n * Cin + chc);
+                    const float4 pb = *(const float4*)(a.pro_b + (size_t)n * Cin + chc);
+                    v.x = silu_f(fmaf(pa.x, v.x, pb.x)); v.y = silu_f(fmaf(pa.y, v.y, pb.y));
+                    v.z = silu_f(fmaf(pa.z, v.z, pb.z)); v.w = silu_f(fmaf(pa.w, v.w, pb.w));
+                } else if (PRO == PRO_LN) {
+                    const float4 g = *(const float4*)(a.pro_a + chc);
+                    const float2 st2 = rst[k];
+                    v.x = g.x * (v.x * st2.x - st2.y); v.y = g.y * (v.y * st2.x - st2.y);
+                    v.z = g.z * (v.z * st2.x - st2.y); v.w = g.w * (v.w * st2.x - st2.y);
+                }
+                if (!okx[k]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(sx + hp * 64 + c4) = v;
+            }
+        }
+    };
+    if (t_beg < t_end) issue(t_beg);
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        __syncthreads();                               // previous tile's MFMAs are done with the LDS
+        commit(tl);
         __syncthreads();
+        issue(tl + 1);                                 // in flight during this tile's MFMAs
         // ---- MFMA: for every pixel pair, A = dY[pixel][co], B = X[pixel shifted by tap][ci] ----
         const float* pa_ = sdy + wc * 32 + c;
         const float* pb_ = sx + wi * 32 + c + ky0 * HC * 64;
