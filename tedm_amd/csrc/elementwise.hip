@@ -365,6 +365,30 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ st,
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= J) return;
     const float bj = bf[j];
+    // the weight row is read once (tdim <= 256: four values per lane), the batch loop runs four samples at a time so that their
+    // loads and wave reductions overlap (one sample at a time left the kernel at 48 us for 8 MB of weights)
+    float wr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = lane + 64 * i < tdim ? wf[(size_t)j * tdim + lane + 64 * i] : 0.f;
+    if (tdim <= 256) {
+        for (int b0 = 0; b0 < B; b0 += 4) {
+            float s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u < B ? b0 + u : B - 1;
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t = fmaf(wr[i], lane + 64 * i < tdim ? st[(size_t)b * tdim + lane + 64 * i] : 0.f, t);
+                s[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = wave_sum(s[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (lane == 0 && b0 + u < B) film[(size_t)(b0 + u) * J + j] = s[u] + bj;
+        }
+        return;
+    }
     for (int b = 0; b < B; ++b) {
         float s = 0.f;
         for (int k = lane; k < tdim; k += 64) s = fmaf(wf[(size_t)j * tdim + k], st[(size_t)b * tdim + k], s);
@@ -708,8 +732,10 @@ __global__ __launch_bounds__(256) void final_fold_kernel(const float* __restrict
     for (int i = threadIdx.x; i < OD * (Cin + 1); i += blockDim.x) {
         const int o = i / (Cin + 1), j = i - o * (Cin + 1);
         float s = 0.f;
-        if (j < Cin) { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], wres[(size_t)c * Cin + j], s); }
-        else { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], bres ? bres[c] : 0.f, s); s += bf ? bf[o] : 0.f; }
+        if (j < Cin) {
+#pragma unroll 16
+            for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], wres[(size_t)c * Cin + j], s);     // (16 loads in flight: the loop was a chain of C latencies)
+        } else { for (int c = 0; c < C; ++c) s = fmaf(wf[o * C + c], bres ? bres[c] : 0.f, s); s += bf ? bf[o] : 0.f; }
         wfold[(size_t)o * (Cin + 4) + j] = s;
     }
 }
